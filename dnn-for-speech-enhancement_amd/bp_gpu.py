@@ -1,0 +1,265 @@
+"""Host-side mirror of the reference's `BP_GPU` class (BP_GPU.h:40-88) over the C ABI in
+include/bp_c_api.h (ctypes binding of libbp_hip.so, the gfx950 HIP library).
+
+Same constructor argument order, method names, argument meaning and error behaviour as the
+reference object so callers/tests read like `BPtrain.cc`:
+
+    obj = BP_GPU(gpu_used, numlayers, layersizes, bunchsize, lrate, momentum, weightcost,
+                 weights, bias, dropoutflag, visible_omit, hid_omit)
+    obj.train(n_frames, indata, targ)             # BP_GPU.cu:241-331
+    err = obj.CrossValid(n_frames, indata, targ)  # BP_GPU.cu:408-479 (SUM of squared errors)
+    obj.returnWeights(weights, bias)              # BP_GPU.cu:910-923
+
+There is NO CPU fallback: if the HIP library is missing or no MI355X is visible the
+constructor raises.  (The reference prints and calls exit(0) on errors, BP_GPU.cu:20-24;
+`strict_exit=True` reproduces that, the default raises BPError so Python callers can react.)
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+MAXLAYER = 10          # BP_GPU.h:13
+MAXCACHEFRAME = 200000  # BP_GPU.h:14
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libbp_hip.so")
+
+# every symbol include/bp_c_api.h declares
+ABI_SYMBOLS = [
+    "bp_last_error", "bp_abi_version", "bp_build_target", "bp_create", "bp_destroy", "bp_train_chunk",
+    "bp_cv_chunk", "bp_forward", "bp_get_weights", "bp_get_deltas", "bp_upload_chunk",
+    "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident", "bp_grad_buffer",
+    "bp_apply_update", "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
+]
+
+
+class BPError(RuntimeError):
+    pass
+
+
+class BPConfig(C.Structure):
+    _fields_ = [
+        ("gpu_used", C.c_int), ("numlayers", C.c_int), ("layersizes", C.c_int * MAXLAYER),
+        ("bunchsize", C.c_int), ("lrate", C.c_float), ("momentum", C.c_float), ("weightcost", C.c_float),
+        ("dropoutflag", C.c_int), ("visible_omit", C.c_float), ("hid_omit", C.c_float),
+        ("activation", C.c_int), ("momentum_rule", C.c_int), ("seed", C.c_uint64), ("device", C.c_int),
+        ("global_bunchsize", C.c_int), ("rank_frame_offset", C.c_int), ("max_chunk_frames", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise BPError("HIP library %s not found: build it with `python __graft_entry__.py` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    fpp = C.POINTER(C.POINTER(C.c_float))
+    fp = C.POINTER(C.c_float)
+    hp = C.c_void_p
+    lib.bp_last_error.restype = C.c_char_p
+    lib.bp_build_target.restype = C.c_char_p
+    lib.bp_create.argtypes = [C.POINTER(BPConfig), fpp, fpp, C.POINTER(hp)]
+    lib.bp_destroy.argtypes = [hp]
+    lib.bp_train_chunk.argtypes = [hp, C.c_int, fp, fp]
+    lib.bp_cv_chunk.argtypes = [hp, C.c_int, fp, fp, fp]
+    lib.bp_forward.argtypes = [hp, C.c_int, fp, fp]
+    lib.bp_get_weights.argtypes = [hp, fpp, fpp]
+    lib.bp_get_deltas.argtypes = [hp, fpp, fpp]
+    lib.bp_upload_chunk.argtypes = [hp, C.c_int, fp, fp]
+    lib.bp_fill_chunk_synthetic.argtypes = [hp, C.c_int, C.c_uint64]
+    lib.bp_train_resident.argtypes = [hp, C.c_int, C.c_int]
+    lib.bp_sync.argtypes = [hp]
+    lib.bp_grads_resident.argtypes = [hp, C.c_int]
+    lib.bp_grad_buffer.argtypes = [hp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.bp_apply_update.argtypes = [hp]
+    lib.bp_use_grad_buffer.argtypes = [hp, C.c_void_p, C.c_size_t]
+    lib.bp_grad_floats.argtypes = [hp, C.POINTER(C.c_size_t)]
+    lib.bp_grad_layout.argtypes = [hp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.bp_set_stream.argtypes = [hp, C.c_void_p]
+    lib.bp_last_train_ms.argtypes = [hp, fp, C.POINTER(C.c_int)]
+    lib.bp_time_kernel.argtypes = [hp, C.c_int, C.c_int, fp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ptrs(arrs):
+    P = C.POINTER(C.c_float)
+    out = (P * MAXLAYER)()
+    for i, a in enumerate(arrs):
+        if a is not None:
+            out[i] = a.ctypes.data_as(P)
+    return out
+
+
+class BP_GPU(object):
+    """Drop-in for the reference trainer object; see module docstring."""
+
+    def __init__(self, gpu_used, numlayers, layersizes, bunchsize, lrate, momentum, weightcost, weights, bias,
+                 dropoutflag=0, visible_omit=0.0, hid_omit=0.0, activation=0, momentum_rule=0, seed=0, device=0,
+                 global_bunchsize=0, rank_frame_offset=0, max_chunk_frames=0, strict_exit=False):
+        self._h = None
+        self._strict = strict_exit
+        self._lib = load_library()
+        self.numlayers = int(numlayers)
+        self.layersizes = [int(x) for x in list(layersizes)[:numlayers]]
+        self.bunchsize = int(bunchsize)
+        self.lrate, self.momentum, self.weightcost = float(lrate), float(momentum), float(weightcost)
+        self.dropoutflag, self.visible_omit, self.hid_omit = int(dropoutflag), float(visible_omit), float(hid_omit)
+        cfg = BPConfig()
+        cfg.gpu_used, cfg.numlayers, cfg.bunchsize = int(gpu_used), self.numlayers, self.bunchsize
+        for i, s in enumerate(self.layersizes[:MAXLAYER]):
+            cfg.layersizes[i] = s
+        cfg.lrate, cfg.momentum, cfg.weightcost = self.lrate, self.momentum, self.weightcost
+        cfg.dropoutflag, cfg.visible_omit, cfg.hid_omit = self.dropoutflag, self.visible_omit, self.hid_omit
+        cfg.activation, cfg.momentum_rule, cfg.seed, cfg.device = int(activation), int(momentum_rule), int(seed), int(device)
+        cfg.global_bunchsize, cfg.rank_frame_offset = int(global_bunchsize), int(rank_frame_offset)
+        cfg.max_chunk_frames = int(max_chunk_frames)
+        self._cfg = cfg
+        if len(self.layersizes) != self.numlayers or self.numlayers < 2 or self.numlayers > MAXLAYER - 1:
+            self._fail("numlayers must be in 2..%d and match layersizes" % (MAXLAYER - 1))
+        w = [None] * MAXLAYER
+        b = [None] * MAXLAYER
+        for l in range(1, self.numlayers):
+            w[l] = np.ascontiguousarray(weights[l], dtype=np.float32).reshape(-1)
+            b[l] = np.ascontiguousarray(bias[l], dtype=np.float32).reshape(-1)
+            if w[l].size != self.layersizes[l - 1] * self.layersizes[l] or b[l].size != self.layersizes[l]:
+                self._fail("weights[%d]/bias[%d] have the wrong size" % (l, l))
+        h = C.c_void_p()
+        self._check(self._lib.bp_create(C.byref(cfg), _ptrs(w), _ptrs(b), C.byref(h)))
+        self._h = h
+
+    # ------------------------------------------------------------------ errors
+    def _fail(self, msg):
+        if self._strict:                      # reference convention: printf + exit(0)
+            print(msg)
+            sys.exit(0)
+        raise BPError(msg)
+
+    def _check(self, rc):
+        if rc != 0:
+            self._fail("%s (status %d)" % (self._lib.bp_last_error().decode(), rc))
+
+    def _in(self, a, n_frames, width, name):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.size < n_frames * width:
+            self._fail("%s holds %d floats, need %d" % (name, a.size, n_frames * width))
+        return a
+
+    # ------------------------------------------------------------------ reference API
+    def train(self, n_frames, indata, targ):
+        x = self._in(indata, n_frames, self.layersizes[0], "in")
+        t = self._in(targ, n_frames, self.layersizes[-1], "targ")
+        self._check(self._lib.bp_train_chunk(self._h, int(n_frames), _fp(x), _fp(t)))
+
+    def CrossValid(self, n_frames, indata, targ):
+        x = self._in(indata, n_frames, self.layersizes[0], "in")
+        t = self._in(targ, n_frames, self.layersizes[-1], "targ")
+        e = C.c_float(0.0)
+        self._check(self._lib.bp_cv_chunk(self._h, int(n_frames), _fp(x), _fp(t), C.byref(e)))
+        return float(e.value)
+
+    def returnWeights(self, weights, bias):
+        """Fills caller-owned arrays weights[l]/bias[l], l = 1..numlayers-1 (index 0 unused)."""
+        for l in range(1, self.numlayers):
+            for a, n in ((weights[l], self.layersizes[l - 1] * self.layersizes[l]), (bias[l], self.layersizes[l])):
+                if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous and a.size == n):
+                    self._fail("returnWeights: arrays must be contiguous float32 of the layer's size")
+        self._check(self._lib.bp_get_weights(self._h, _ptrs(weights), _ptrs(bias)))
+
+    # ------------------------------------------------------------------ conveniences / extensions
+    def _new_params(self):
+        w = [None] + [np.empty((self.layersizes[l - 1], self.layersizes[l]), np.float32) for l in range(1, self.numlayers)]
+        b = [None] + [np.empty(self.layersizes[l], np.float32) for l in range(1, self.numlayers)]
+        return w, b
+
+    def get_weights(self):
+        w, b = self._new_params()
+        self.returnWeights(w, b)
+        return w, b
+
+    def get_deltas(self):
+        w, b = self._new_params()
+        self._check(self._lib.bp_get_deltas(self._h, _ptrs(w), _ptrs(b)))
+        return w, b
+
+    def forward(self, indata):
+        x = np.ascontiguousarray(indata, dtype=np.float32).reshape(-1, self.layersizes[0])
+        out = np.empty((x.shape[0], self.layersizes[-1]), np.float32)
+        self._check(self._lib.bp_forward(self._h, x.shape[0], _fp(x), _fp(out)))
+        return out
+
+    def upload_chunk(self, indata, targ):
+        x = np.ascontiguousarray(indata, dtype=np.float32).reshape(-1, self.layersizes[0])
+        t = self._in(targ, x.shape[0], self.layersizes[-1], "targ")
+        self._check(self._lib.bp_upload_chunk(self._h, x.shape[0], _fp(x), _fp(t)))
+
+    def fill_chunk_synthetic(self, n_frames, seed=20260927):
+        self._check(self._lib.bp_fill_chunk_synthetic(self._h, int(n_frames), int(seed)))
+
+    def train_resident(self, first_frame, n_frames):
+        self._check(self._lib.bp_train_resident(self._h, int(first_frame), int(n_frames)))
+
+    def grads_resident(self, first_frame):
+        self._check(self._lib.bp_grads_resident(self._h, int(first_frame)))
+
+    def apply_update(self):
+        self._check(self._lib.bp_apply_update(self._h))
+
+    def grad_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.bp_grad_buffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def grad_floats(self):
+        n = C.c_size_t()
+        self._check(self._lib.bp_grad_floats(self._h, C.byref(n)))
+        return n.value
+
+    def use_grad_buffer(self, device_ptr, n_floats):
+        self._check(self._lib.bp_use_grad_buffer(self._h, C.c_void_p(device_ptr), int(n_floats)))
+
+    def grad_layout(self, layer):
+        o, c = C.c_size_t(), C.c_size_t()
+        self._check(self._lib.bp_grad_layout(self._h, int(layer), C.byref(o), C.byref(c)))
+        return o.value, c.value
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(self._lib.bp_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def sync(self):
+        self._check(self._lib.bp_sync(self._h))
+
+    def last_train_ms(self):
+        ms, nb = C.c_float(), C.c_int()
+        self._check(self._lib.bp_last_train_ms(self._h, C.byref(ms), C.byref(nb)))
+        return float(ms.value), int(nb.value)
+
+    def time_kernel(self, which, iters=50):
+        ms = C.c_float()
+        self._check(self._lib.bp_time_kernel(self._h, int(which), int(iters), C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self._h is not None:
+            self._lib.bp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,566 @@
+// bp_engine.hip -- C-ABI implementation (include/bp_c_api.h): device state of one BP_GPU
+// replacement object and the per-bunch launch sequence.  gfx950 only.
+//
+// Device layout (all fp32): every layer width s_l is padded to ld_l = roundup(s_l, 64); pad
+// columns/rows are zero and stay zero under the step (DESIGN.md "padding invariants"), so the
+// GEMM tiles never need column predicates and every row is 256-byte aligned.
+//   W_l   [ld_{l-1}][ld_l]   (reference layout weights[l][p*cur+c], BP_GPU.cu:139)
+//   y_l   [B][ld_l]          post-activation, post-dropout output of layer l (layer_y)
+//   dx_l  [B][ld_l]          dE/dx of layer l (layer_dedx); layer_x/dydx/dedy are never stored
+//   in    [cap][ld_0], targ [cap][ld_{L-1}]   resident chunk (dev.in/dev.targ, BP_GPU.cu:127-130)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bp_c_api.h"
+#include "bp_kernels.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                     \
+    do {                                                                                              \
+        hipError_t _e = (x);                                                                          \
+        if (_e != hipSuccess)                                                                         \
+            return fail(BP_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+static inline int pad64(int x) { return (x + 63) & ~63; }
+
+struct bp_handle {
+    bp_config cfg;
+    int L;                       // number of layer sizes
+    int s[BP_MAXLAYER], ld[BP_MAXLAYER];
+    int B, Bg;                   // local / global bunch
+    int cap, chunk_frames;
+    hipStream_t own_stream, stream;
+    float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
+    float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
+    float *in, *in_drop, *targ, *out_dev;
+    float *grad; size_t grad_floats; size_t g_off[BP_MAXLAYER], g_cnt[BP_MAXLAYER];
+    float *host_out;             // pinned staging for CV outputs
+    uint32_t step;               // bunches trained so far (dropout stream position)
+    long mask_lo, mask_hi; uint32_t mask_step0;
+    uint32_t th_vis, th_hid;
+    hipEvent_t ev0, ev1; float last_ms; int last_bunches;
+    std::vector<void *> allocs;
+};
+
+static uint32_t drop_threshold(float p)
+{
+    double t = (double)p * 4294967296.0;
+    if (t <= 0.0) return 0u;
+    if (t >= 4294967295.0) return 4294967295u;
+    return (uint32_t)t;
+}
+
+extern "C" const char *bp_last_error(void) { return g_err.c_str(); }
+extern "C" int bp_abi_version(void) { return 1; }
+extern "C" const char *bp_build_target(void) { return "gfx950"; }
+
+static int dev_alloc(bp_handle *h, float **p, size_t n_floats)
+{
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, n_floats * sizeof(float));
+    if (e != hipSuccess) return fail(BP_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemsetAsync(q, 0, n_floats * sizeof(float), h->stream);
+    if (e != hipSuccess) return fail(BP_ERR_DEVICE, std::string("hipMemset: ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (float *)q;
+    return BP_OK;
+}
+
+extern "C" int bp_destroy(bp_handle *h)
+{
+    if (!h) return BP_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->host_out) (void)hipHostFree(h->host_out);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return BP_OK;
+}
+
+extern "C" int bp_create(const bp_config *cfg, const float *const *weights, const float *const *bias,
+                         bp_handle **out)
+{
+    if (!cfg || !weights || !bias || !out) return fail(BP_ERR_ARG, "bp_create: null argument");
+    // WorkPara holds weights[MAXLAYER-1] indexed 1..numlayers-1 (Interface.h:44-45) => L <= 9
+    if (cfg->numlayers < 2 || cfg->numlayers > BP_MAXLAYER - 1)
+        return fail(BP_ERR_ARG, "bp_create: numlayers must be in 2..9");
+    if (cfg->bunchsize < 1) return fail(BP_ERR_ARG, "bp_create: bunchsize must be >= 1");
+    if (cfg->gpu_used < 1) return fail(BP_ERR_ARG, "bp_create: gpu_used must be >= 1");  // BP_GPU.cu:20-24
+    for (int l = 0; l < cfg->numlayers; ++l)
+        if (cfg->layersizes[l] < 1) return fail(BP_ERR_ARG, "bp_create: layer size must be >= 1");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(BP_ERR_ARG, "bp_create: device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+
+    bp_handle *h = new bp_handle();
+    memset((void *)&h->cfg, 0, sizeof(h->cfg));
+    h->cfg = *cfg;
+    h->L = cfg->numlayers;
+    h->B = cfg->bunchsize;
+    h->Bg = cfg->global_bunchsize > 0 ? cfg->global_bunchsize : cfg->bunchsize;
+    h->cap = cfg->max_chunk_frames > 0 ? cfg->max_chunk_frames : BP_MAXCACHEFRAME;
+    if (h->cap < h->B) h->cap = h->B;
+    h->chunk_frames = 0;
+    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0;
+    h->th_vis = cfg->dropoutflag == 1 ? drop_threshold(cfg->visible_omit) : 0u;
+    h->th_hid = cfg->dropoutflag == 1 ? drop_threshold(cfg->hid_omit) : 0u;
+    if (cfg->dropoutflag == 1 && (h->B % 4 != 0 || cfg->rank_frame_offset % 4 != 0)) {
+        delete h;
+        return fail(BP_ERR_ARG, "bp_create: dropout needs bunchsize and rank_frame_offset to be multiples of 4");
+    }
+    for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
+    h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr;
+    h->last_ms = 0.f; h->last_bunches = 0;
+
+#define CK(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_err; bp_destroy(h); g_err = m; return _r; } } while (0)
+#define HK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(_e); bp_destroy(h); return fail(BP_ERR_DEVICE, m); } } while (0)
+    HK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    HK(hipEventCreate(&h->ev0));
+    HK(hipEventCreate(&h->ev1));
+    const int L = h->L;
+    CK(dev_alloc(h, &h->in, (size_t)h->cap * h->ld[0]));
+    if (cfg->dropoutflag == 1 && h->th_vis) CK(dev_alloc(h, &h->in_drop, (size_t)h->cap * h->ld[0]));
+    CK(dev_alloc(h, &h->targ, (size_t)h->cap * h->ld[L - 1]));
+    CK(dev_alloc(h, &h->out_dev, (size_t)h->B * h->ld[L - 1]));
+    HK(hipHostMalloc((void **)&h->host_out, (size_t)h->B * h->ld[L - 1] * sizeof(float)));
+    size_t goff = 0;
+    for (int l = 1; l < L; ++l) {
+        const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
+        CK(dev_alloc(h, &h->W[l], nw));
+        CK(dev_alloc(h, &h->dW[l], nw));
+        CK(dev_alloc(h, &h->b[l], h->ld[l]));
+        CK(dev_alloc(h, &h->db[l], h->ld[l]));
+        CK(dev_alloc(h, &h->y[l], (size_t)h->B * h->ld[l]));
+        CK(dev_alloc(h, &h->dx[l], (size_t)h->B * h->ld[l]));
+        h->g_off[l] = goff; h->g_cnt[l] = nw + h->ld[l]; goff += h->g_cnt[l];
+    }
+    h->grad_floats = goff;
+    if (h->Bg != h->B) CK(dev_alloc(h, &h->grad, goff));   // otherwise allocated on first bp_grads_resident
+    for (int l = 1; l < L; ++l) {
+        if (!weights[l] || !bias[l]) { bp_destroy(h); return fail(BP_ERR_ARG, "bp_create: weights[l]/bias[l] null"); }
+        HK(hipMemcpy2DAsync(h->W[l], (size_t)h->ld[l] * 4, weights[l], (size_t)h->s[l] * 4, (size_t)h->s[l] * 4,
+                            h->s[l - 1], hipMemcpyHostToDevice, h->stream));
+        HK(hipMemcpyAsync(h->b[l], bias[l], (size_t)h->s[l] * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    HK(hipStreamSynchronize(h->stream));
+#undef CK
+#undef HK
+    *out = h;
+    return BP_OK;
+}
+
+extern "C" int bp_set_stream(bp_handle *h, void *hip_stream)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return BP_OK;
+}
+
+extern "C" int bp_sync(bp_handle *h)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BP_OK;
+}
+
+// ------------------------------------------------------------------ launches
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI>
+static hipError_t launch(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N)
+{
+    g.tiles_m = (M + BM - 1) / BM;
+    g.tiles_n = (N + BN - 1) / BN;
+    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, st,
+                       g, e);
+    return hipGetLastError();
+}
+
+static EpiArgs epi_zero()
+{
+    EpiArgs e;
+    memset(&e, 0, sizeof(e));
+    e.alpha = 1.0f;
+    return e;
+}
+
+// forward of weight layer l on M frames.  y_prev [M][ld_{l-1}].  train: hidden outputs get the
+// hid_omit mask; output layer writes dEdX_L (and out when out != null).
+static hipError_t launch_fwd(bp_handle *h, int l, int M, const float *y_prev, const float *targ, float *out,
+                             bool train, float alpha)
+{
+    const int L = h->L, prev = h->ld[l - 1], cur = h->ld[l];
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = y_prev; g.lda = prev; g.B = h->W[l]; g.ldb = cur; g.K = prev;
+    g.a_row_limit = M; g.a_col_limit = prev; g.b_row_limit = prev; g.b_col_limit = cur;
+    EpiArgs e = epi_zero();
+    e.m_limit = M; e.n_limit = cur; e.n_true = h->s[l]; e.bias = h->b[l]; e.alpha = alpha; e.act = h->cfg.activation;
+    if (l != L - 1) {
+        e.C = h->y[l]; e.ldc = cur;
+        e.drop_thresh = train ? h->th_hid : 0u;
+        e.seed_lo = (uint32_t)h->cfg.seed; e.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+        e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
+        if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_HIDDEN>(h->stream, g, e, M, cur);
+        return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>(h->stream, g, e, M, cur);
+    }
+    e.C = train ? h->dx[l] : nullptr; e.ldc = cur;
+    e.aux = targ; e.ldaux = cur; e.aux2 = out; e.ldaux2 = cur;
+    e.scale = 2.0f / (float)h->Bg;                       // kernSubClean: 2.0f/rows (global rows under DP)
+    if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_OUT>(h->stream, g, e, M, cur);
+    return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_OUT>(h->stream, g, e, M, cur);
+}
+
+// dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T)     (BP_GPU.cu:611-637)
+static hipError_t launch_dgrad(bp_handle *h, int l, int M)
+{
+    const int prev = h->ld[l - 1], cur = h->ld[l];
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = h->dx[l]; g.lda = cur; g.B = h->W[l]; g.ldb = cur; g.K = cur;
+    g.a_row_limit = M; g.a_col_limit = cur; g.b_row_limit = prev; g.b_col_limit = cur;
+    EpiArgs e = epi_zero();
+    e.C = h->dx[l - 1]; e.ldc = prev; e.m_limit = M; e.n_limit = prev; e.n_true = h->s[l - 1];
+    e.aux = h->y[l - 1]; e.ldaux = prev; e.act = h->cfg.activation;
+    if (prev <= 512) return launch<32, 32, 64, 1, 1, true, true, EPI_DGRAD>(h->stream, g, e, M, prev);
+    return launch<32, 64, 64, 1, 2, true, true, EPI_DGRAD>(h->stream, g, e, M, prev);
+}
+
+// G_l = y_{l-1}^T . dEdX_l, gb_l = colsum(dEdX_l); fused momentum update (single device) or
+// store into the flat gradient buffer (data parallel).   (BP_GPU.cu:642-652)
+static hipError_t launch_wgrad(bp_handle *h, int l, int M, const float *y_prev, bool fused)
+{
+    const int prev = h->ld[l - 1], cur = h->ld[l];
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = y_prev; g.lda = prev; g.B = h->dx[l]; g.ldb = cur; g.K = M;
+    g.a_row_limit = M; g.a_col_limit = prev; g.b_row_limit = M; g.b_col_limit = cur;
+    EpiArgs e = epi_zero();
+    e.ldc = cur; e.m_limit = prev; e.n_limit = cur; e.n_true = h->s[l];
+    if (fused) {
+        const float m = h->cfg.momentum, lr = h->cfg.lrate;
+        e.C = h->W[l]; e.aux2 = h->dW[l]; e.ldaux2 = cur;
+        e.mom = m; e.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; e.wc = h->cfg.weightcost;
+        e.ndiv = (float)h->Bg;
+        e.bias_w = h->b[l]; e.bias_d = h->db[l];
+        return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE>(h->stream, g, e, prev, cur);
+    }
+    e.C = h->grad + h->g_off[l];
+    e.bias_g = h->grad + h->g_off[l] + (size_t)prev * cur;
+    return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_STORE>(h->stream, g, e, prev, cur);
+}
+
+static hipError_t mask_range(bp_handle *h, int first, int n)
+{
+    if (!h->in_drop || n <= 0) return hipSuccess;
+    dim3 grid((h->ld[0] + 255) / 256, (n + 3) / 4);
+    hipLaunchKernelGGL(bp_mask_input, grid, dim3(256), 0, h->stream, h->in, h->in_drop, h->ld[0], h->s[0], first, n,
+                       h->B, h->cfg.rank_frame_offset, h->th_vis, (uint32_t)h->cfg.seed,
+                       (uint32_t)(h->cfg.seed >> 32), h->step);
+    h->mask_lo = first; h->mask_hi = (long)first + n; h->mask_step0 = h->step;
+    return hipGetLastError();
+}
+
+// One bunch starting at chunk frame `first`: forward + backward.  fused: momentum update inside
+// the wgrad epilogues (train_bunch_single); else gradients to the flat buffer.
+static hipError_t bunch(bp_handle *h, int first, bool fused)
+{
+    const int L = h->L, B = h->B;
+    hipError_t er;
+    const float *x0 = h->in + (size_t)first * h->ld[0];
+    if (h->in_drop) {
+        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
+                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
+                        (first - h->mask_lo) % B == 0;
+        if (!ok) { er = mask_range(h, first, B); if (er != hipSuccess) return er; }
+        x0 = h->in_drop + (size_t)first * h->ld[0];
+    }
+    const float *tg = h->targ + (size_t)first * h->ld[L - 1];
+    for (int l = 1; l < L; ++l) {
+        er = launch_fwd(h, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f);
+        if (er != hipSuccess) return er;
+    }
+    for (int l = L - 1; l >= 1; --l) {
+        if (l != 1) { er = launch_dgrad(h, l, B); if (er != hipSuccess) return er; }
+        er = launch_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
+        if (er != hipSuccess) return er;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ chunk interface
+extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, const float *targ)
+{
+    if (!h || !in) return fail(BP_ERR_ARG, "bp_upload_chunk: null argument");
+    if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_upload_chunk: n_frames exceeds chunk capacity");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int L = h->L;
+    if (n_frames > 0) {
+        HIPCHK(hipMemcpy2DAsync(h->in, (size_t)h->ld[0] * 4, in, (size_t)h->s[0] * 4, (size_t)h->s[0] * 4, n_frames,
+                                hipMemcpyHostToDevice, h->stream));
+        if (targ)
+            HIPCHK(hipMemcpy2DAsync(h->targ, (size_t)h->ld[L - 1] * 4, targ, (size_t)h->s[L - 1] * 4,
+                                    (size_t)h->s[L - 1] * 4, n_frames, hipMemcpyHostToDevice, h->stream));
+        // the caller may overwrite in/targ as soon as we return (BPtrain.cc:50-53)
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->chunk_frames = n_frames;
+    h->mask_lo = h->mask_hi = -1;
+    return BP_OK;
+}
+
+extern "C" int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_fill_chunk_synthetic: n_frames exceeds capacity");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int L = h->L;
+    if (n_frames > 0) {
+        size_t n4 = (size_t)n_frames * (h->ld[0] / 4);
+        hipLaunchKernelGGL(bp_fill_normal, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->stream, h->in, h->ld[0],
+                           h->s[0], n_frames, (uint32_t)seed, (uint32_t)(seed >> 32), 0u);
+        HIPCHK(hipGetLastError());
+        n4 = (size_t)n_frames * (h->ld[L - 1] / 4);
+        hipLaunchKernelGGL(bp_fill_normal, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->stream, h->targ,
+                           h->ld[L - 1], h->s[L - 1], n_frames, (uint32_t)seed, (uint32_t)(seed >> 32), 1u);
+        HIPCHK(hipGetLastError());
+    }
+    h->chunk_frames = n_frames;
+    h->mask_lo = h->mask_hi = -1;
+    return BP_OK;
+}
+
+extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (first_frame < 0 || n_frames < 0 || first_frame + n_frames > h->chunk_frames)
+        return fail(BP_ERR_ARG, "bp_train_resident: frame range outside the resident chunk");
+    if (h->Bg != h->B) return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle, use bp_grads_resident + bp_apply_update");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int nb = n_frames / h->B;          // partial last bunch ignored (BP_GPU.cu:315-318)
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    if (nb > 0 && h->in_drop) HIPCHK(mask_range(h, first_frame, nb * h->B));
+    for (int i = 0; i < nb; ++i) {
+        HIPCHK(bunch(h, first_frame + i * h->B, true));
+        h->step++;
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    h->last_bunches = nb;
+    return BP_OK;
+}
+
+extern "C" int bp_last_train_ms(bp_handle *h, float *ms, int *bunches)
+{
+    if (!h || !ms) return fail(BP_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    if (bunches) *bunches = h->last_bunches;
+    return BP_OK;
+}
+
+extern "C" int bp_train_chunk(bp_handle *h, int n_frames, const float *in, const float *targ)
+{
+    if (!h || !in || !targ) return fail(BP_ERR_ARG, "bp_train_chunk: null argument");
+    int r = bp_upload_chunk(h, n_frames, in, targ);
+    if (r != BP_OK) return r;
+    if (n_frames % h->B)
+        printf("this bunch has only %d samples and is ignored.\n", n_frames % h->B);   // BP_GPU.cu:317
+    return bp_train_resident(h, 0, n_frames);
+}
+
+// ------------------------------------------------------------------ data-parallel split
+extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
+    if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
+        return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(bunch(h, first_frame, false));
+    return BP_OK;
+}
+
+extern "C" int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats)
+{
+    if (!h || !device_ptr || !n_floats) return fail(BP_ERR_ARG, "null argument");
+    if (!h->grad) { HIPCHK(hipSetDevice(h->cfg.device)); int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
+    *device_ptr = h->grad; *n_floats = h->grad_floats;
+    return BP_OK;
+}
+
+extern "C" int bp_grad_floats(bp_handle *h, size_t *n_floats)
+{
+    if (!h || !n_floats) return fail(BP_ERR_ARG, "null argument");
+    *n_floats = h->grad_floats;
+    return BP_OK;
+}
+
+extern "C" int bp_use_grad_buffer(bp_handle *h, void *device_ptr, size_t n_floats)
+{
+    if (!h || !device_ptr) return fail(BP_ERR_ARG, "null argument");
+    if (n_floats != h->grad_floats) return fail(BP_ERR_ARG, "bp_use_grad_buffer: size must equal bp_grad_floats");
+    if (((uintptr_t)device_ptr & 15) != 0) return fail(BP_ERR_ARG, "bp_use_grad_buffer: pointer must be 16-byte aligned");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->grad = (float *)device_ptr;        // not in h->allocs: never freed here
+    return BP_OK;
+}
+
+extern "C" int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *count)
+{
+    if (!h || layer < 1 || layer >= h->L || !offset || !count) return fail(BP_ERR_ARG, "bp_grad_layout: bad argument");
+    *offset = h->g_off[layer]; *count = h->g_cnt[layer];
+    return BP_OK;
+}
+
+extern "C" int bp_apply_update(bp_handle *h)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (!h->grad) return fail(BP_ERR_STATE, "bp_apply_update: no gradients (call bp_grads_resident first)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const float m = h->cfg.momentum, lr = h->cfg.lrate;
+    const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
+    for (int l = h->L - 1; l >= 1; --l) {
+        const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
+        const float *g = h->grad + h->g_off[l];
+        hipLaunchKernelGGL(bp_update_flat, dim3(2048), dim3(256), 0, h->stream, h->W[l], h->dW[l], g, nw, h->b[l],
+                           h->db[l], g + nw, h->ld[l], m, c1, h->cfg.weightcost, (float)h->Bg);
+        HIPCHK(hipGetLastError());
+    }
+    h->step++;
+    return BP_OK;
+}
+
+// ------------------------------------------------------------------ inference / CV
+static int forward_bunch(bp_handle *h, int first, int fb)
+{
+    const int L = h->L;
+    const float vis_keep = 1.0f - h->cfg.visible_omit, hid_keep = 1.0f - h->cfg.hid_omit;   // BP_GPU.cu:703-704
+    for (int l = 1; l < L; ++l) {
+        float alpha = 1.0f;
+        if (h->cfg.dropoutflag == 1) alpha = (l == 1) ? vis_keep : hid_keep;
+        const float *yp = (l == 1) ? h->in + (size_t)first * h->ld[0] : h->y[l - 1];
+        HIPCHK(launch_fwd(h, l, fb, yp, nullptr, h->out_dev, false, alpha));
+    }
+    return BP_OK;
+}
+
+extern "C" int bp_forward(bp_handle *h, int n_frames, const float *in, float *out)
+{
+    if (!h || !in || !out) return fail(BP_ERR_ARG, "bp_forward: null argument");
+    int r = bp_upload_chunk(h, n_frames, in, nullptr);
+    if (r != BP_OK) return r;
+    const int L = h->L, sL = h->s[L - 1], ldL = h->ld[L - 1];
+    for (int i = 0; i < n_frames; i += h->B) {
+        const int fb = h->B > n_frames - i ? n_frames - i : h->B;
+        r = forward_bunch(h, i, fb);
+        if (r != BP_OK) return r;
+        HIPCHK(hipMemcpy2DAsync(out + (size_t)i * sL, (size_t)sL * 4, h->out_dev, (size_t)ldL * 4, (size_t)sL * 4, fb,
+                                hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return BP_OK;
+}
+
+extern "C" int bp_cv_chunk(bp_handle *h, int n_frames, const float *in, const float *targ, float *sq_err_sum)
+{
+    if (!h || !in || !targ || !sq_err_sum) return fail(BP_ERR_ARG, "bp_cv_chunk: null argument");
+    int r = bp_upload_chunk(h, n_frames, in, nullptr);
+    if (r != BP_OK) return r;
+    const int L = h->L, sL = h->s[L - 1], ldL = h->ld[L - 1];
+    float squared_err = 0.0f;
+    for (int i = 0; i < n_frames; i += h->B) {          // partial bunch processed (BP_GPU.cu:450-453)
+        const int fb = h->B > n_frames - i ? n_frames - i : h->B;
+        r = forward_bunch(h, i, fb);
+        if (r != BP_OK) return r;
+        HIPCHK(hipMemcpyAsync(h->host_out, h->out_dev, (size_t)fb * ldL * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        const float *t = targ + (size_t)i * sL;
+        for (int j = 0; j < fb; ++j)                     // fp32, frame-major / bin-minor (BP_GPU.cu:458-467)
+            for (int d = 0; d < sL; ++d) {
+                const float e = h->host_out[(size_t)j * ldL + d] - t[(size_t)j * sL + d];
+                squared_err = squared_err + e * e;
+            }
+    }
+    *sq_err_sum = squared_err;
+    return BP_OK;
+}
+
+static int get_params(bp_handle *h, float *const *w, float *const *b, bool deltas)
+{
+    if (!h || !w || !b) return fail(BP_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (int l = 1; l < h->L; ++l) {
+        if (!w[l] || !b[l]) return fail(BP_ERR_ARG, "weights[l]/bias[l] null");
+        HIPCHK(hipMemcpy2DAsync(w[l], (size_t)h->s[l] * 4, deltas ? h->dW[l] : h->W[l], (size_t)h->ld[l] * 4,
+                                (size_t)h->s[l] * 4, h->s[l - 1], hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(b[l], deltas ? h->db[l] : h->b[l], (size_t)h->s[l] * 4, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));    // reference relies on pageable-copy semantics (BP_GPU.cu:920-921)
+    return BP_OK;
+}
+extern "C" int bp_get_weights(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, false); }
+extern "C" int bp_get_deltas(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, true); }
+
+// ------------------------------------------------------------------ isolated kernel timing
+extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
+{
+    if (!h || !avg_ms || iters < 1) return fail(BP_ERR_ARG, "bp_time_kernel: bad argument");
+    if (h->L < 4 && (which == 0 || which == 1 || which == 2))
+        return fail(BP_ERR_ARG, "bp_time_kernel: needs a hidden->hidden layer (numlayers >= 4)");
+    if (h->chunk_frames < h->B) return fail(BP_ERR_STATE, "bp_time_kernel: no resident chunk");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int L = h->L, B = h->B;
+    hipEvent_t a, b;
+    float *scratch_w = nullptr, *scratch_d = nullptr, *scratch_b = nullptr;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    for (int it = -2; it < iters; ++it) {
+        if (it == 0) HIPCHK(hipEventRecord(a, h->stream));
+        hipError_t er = hipSuccess;
+        switch (which) {
+        case 0: er = launch_fwd(h, 2, B, h->y[1], nullptr, nullptr, true, 1.0f); break;
+        case 1: er = launch_dgrad(h, 3 < L ? 3 : 2, B); break;
+        case 2: case 5: {
+            // wgrad + fused update on scratch copies of W / delta (same traffic, state untouched)
+            const int l = which == 2 ? 2 : 1;
+            const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
+            if (!scratch_w) {
+                HIPCHK(hipMalloc((void **)&scratch_w, nw * 4)); HIPCHK(hipMalloc((void **)&scratch_d, nw * 4));
+                HIPCHK(hipMalloc((void **)&scratch_b, (size_t)h->ld[l] * 8));
+                HIPCHK(hipMemcpyAsync(scratch_w, h->W[l], nw * 4, hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(hipMemsetAsync(scratch_d, 0, nw * 4, h->stream));
+                HIPCHK(hipMemsetAsync(scratch_b, 0, (size_t)h->ld[l] * 8, h->stream));
+            }
+            float *W0 = h->W[l], *D0 = h->dW[l], *b0 = h->b[l], *db0 = h->db[l];
+            h->W[l] = scratch_w; h->dW[l] = scratch_d; h->b[l] = scratch_b; h->db[l] = scratch_b + h->ld[l];
+            er = launch_wgrad(h, l, B, l == 1 ? h->in : h->y[l - 1], true);
+            h->W[l] = W0; h->dW[l] = D0; h->b[l] = b0; h->db[l] = db0;
+            break;
+        }
+        case 3: er = launch_fwd(h, 1, B, h->in, nullptr, nullptr, true, 1.0f); break;
+        case 4: er = launch_fwd(h, L - 1, B, h->y[L - 2], h->targ, nullptr, true, 1.0f); break;
+        default: HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b));
+                 return fail(BP_ERR_ARG, "bp_time_kernel: unknown kernel id");
+        }
+        HIPCHK(er);
+    }
+    HIPCHK(hipEventRecord(b, h->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *avg_ms = ms / iters;
+    if (scratch_w) { (void)hipFree(scratch_w); (void)hipFree(scratch_d); (void)hipFree(scratch_b); }
+    HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b));
+    return BP_OK;
+}

@@ -1,0 +1,55 @@
+"""Data-parallel driver: one process per GPU, minibatch sharded over ranks, one gradient
+exchange per minibatch (semantics donor = the reference's commented-out
+train_bunch_multi, BP_GPU.cu:775-908: per-GPU fwd/bwd, gradient SUM, one update with
+n = global bunch, identical state on every rank afterwards).
+
+The step engine is pluggable only so that the exchange logic can be exercised by CPU tests
+with a `gloo` process group; the product engine is `HipEngine` (libbp_hip.so) and nothing here
+falls back to a CPU computation.
+"""
+import numpy as np
+
+
+class HipEngine(object):
+    """Per-rank compute engine on the HIP library: gradients of the local shard go to a torch
+    tensor that RCCL reduces in place; all device work runs on torch's current stream so the
+    collective is ordered against it."""
+
+    def __init__(self, pkg, layersizes, local_bunch, world, rank, lrate, momentum, weightcost, weights, bias,
+                 device=0, max_chunk_frames=0, **kw):
+        import torch
+        self.torch = torch
+        self.world, self.rank, self.B = world, rank, local_bunch
+        self.obj = pkg.BP_GPU(world, len(layersizes), layersizes, local_bunch, lrate, momentum, weightcost, weights,
+                              bias, device=device, global_bunchsize=local_bunch * world,
+                              rank_frame_offset=rank * local_bunch, max_chunk_frames=max_chunk_frames, **kw)
+        n = self.obj.grad_floats()
+        self.grad = torch.zeros(n, dtype=torch.float32, device="cuda:%d" % device)
+        self.obj.use_grad_buffer(self.grad.data_ptr(), n)
+        self.obj.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.segments = [self.obj.grad_layout(l) for l in range(1, len(layersizes))]
+
+    def grads(self, first_frame):
+        self.obj.grads_resident(first_frame)
+        return self.grad
+
+    def update(self):
+        self.obj.apply_update()
+
+
+def dp_step(engine, dist, first_frame):
+    """One data-parallel minibatch: local gradients -> all-reduce(SUM) -> identical update."""
+    g = engine.grads(first_frame)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    engine.update()
+
+
+def shard_rows(n_frames, global_bunch, world, rank):
+    """Row indices of `rank`'s shard of every full global bunch of a chunk (partial last bunch
+    dropped as in BP_GPU.cu:315-318): bunch i -> rows [i*Bg + r*Bg/G, i*Bg + (r+1)*Bg/G)."""
+    assert global_bunch % world == 0
+    lb = global_bunch // world
+    nb = n_frames // global_bunch
+    idx = (np.arange(nb)[:, None] * global_bunch + rank * lb + np.arange(lb)[None, :]).reshape(-1)
+    return idx

@@ -1,0 +1,149 @@
+/*
+ * bp_c_api.h -- C ABI of the MI355X-native trainer that replaces the reference's `BP_GPU`
+ * object (the frame-wise DNN forward / backward / momentum-update hot path).
+ *
+ * Every entry point below is what a binding for this path binds.  Each cites the reference
+ * interface it replaces (paths relative to the reference tree).  Plain pointers and sizes
+ * only; no HIP, torch or C++ types.  All functions return 0 on success and a negative
+ * bp_status on failure (the reference instead prints and calls exit(0): BP_GPU.cu:20-24,
+ * 929-933 -- the C++ shim include/BP_GPU.h reproduces that convention on top of this ABI).
+ * bp_last_error() returns the message of the last failure on the calling thread.
+ *
+ * Host data layout (identical to the reference):
+ *   weights[l][p*cur + c]  (l = 1..numlayers-1, index 0 unused, [prev][cur] row-major)
+ *   bias[l][c], in[f*s0 + k], targ[f*sL + d], all fp32 little-endian.
+ * Ownership: the library copies in/out; it never keeps or frees caller pointers.  On return
+ * from bp_train_chunk / bp_cv_chunk the caller may overwrite `in`/`targ` at once (the
+ * reference gives the same guarantee through pageable-memory cublasSetVectorAsync,
+ * BP_GPU.cu:274-276); bp_get_weights returns with the data in place (the reference relies
+ * on pageable-memory semantics at BP_GPU.cu:920-921).
+ */
+#ifndef BP_C_API_H
+#define BP_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BP_MAXLAYER 10          /* BP_GPU.h:13  (#define MAXLAYER 10)           */
+#define BP_MAXCACHEFRAME 200000 /* BP_GPU.h:14  (#define MAXCACHEFRAME 200000)  */
+
+typedef enum {
+    BP_OK = 0,
+    BP_ERR_ARG = -1,     /* bad argument / configuration                         */
+    BP_ERR_DEVICE = -2,  /* HIP runtime error (message has the HIP error string) */
+    BP_ERR_STATE = -3,   /* call not valid in the handle's current state         */
+    BP_ERR_NOMEM = -4
+} bp_status;
+
+/* Constructor arguments of BP_GPU (BP_GPU.h:43-44, BP_GPU.cu:10-12) plus the switches the
+ * reference exposes only by editing source.  A zero-initialised tail reproduces the live
+ * reference behaviour. */
+typedef struct bp_config {
+    int   gpu_used;                 /* a_GPU_selected. Reference: device count; here the ranks of
+                                       a data-parallel job are separate processes, so this is
+                                       informational and must be >= 1                          */
+    int   numlayers;                /* number of layer SIZES (2..9, WorkPara limit Interface.h:44) */
+    int   layersizes[BP_MAXLAYER];
+    int   bunchsize;                /* frames per minibatch handled by THIS device             */
+    float lrate, momentum, weightcost;
+    int   dropoutflag;              /* 1 = dropout on (BP_GPU.cu:534-551)                      */
+    float visible_omit, hid_omit;
+    /* ---- extensions (0 = live reference) ---- */
+    int   activation;               /* 0 ReLU (DevFunc.cu:67-97 live) | 1 Sigmoid (.bak)        */
+    int   momentum_rule;            /* 0 (1-m) rule DevFunc.cu:313-318 | 1 classic :306-311     */
+    uint64_t seed;                  /* dropout Philox key (reference: time(NULL), BP_GPU.cu:77) */
+    int   device;                   /* HIP device ordinal for this handle                       */
+    int   global_bunchsize;         /* data parallel: frames per minibatch over ALL ranks
+                                       (0 = bunchsize).  Scales dEdX_L by 2/global and the
+                                       update by 1/global                        */
+    int   rank_frame_offset;        /* data parallel: index of this rank's first frame inside
+                                       the global bunch (keys the dropout stream)               */
+    int   max_chunk_frames;         /* capacity of the resident chunk cache; 0 = BP_MAXCACHEFRAME */
+} bp_config;
+
+typedef struct bp_handle bp_handle;
+
+const char *bp_last_error(void);
+/* Library/ABI version and the gfx target the kernels were compiled for ("gfx950"). */
+int         bp_abi_version(void);
+const char *bp_build_target(void);
+
+/* BP_GPU::BP_GPU (BP_GPU.cu:10-197): select device, allocate device state, upload weights
+ * and biases (index 1..numlayers-1).  Momentum state starts at zero (devnew_vf zero-fill,
+ * BP_GPU.cu:137-138,938-940). */
+int bp_create(const bp_config *cfg, const float *const *weights, const float *const *bias,
+              bp_handle **out);
+
+/* BP_GPU::~BP_GPU (BP_GPU.cu:199-239). */
+int bp_destroy(bp_handle *h);
+
+/* BP_GPU::train (BP_GPU.cu:241-331): upload a chunk of n_frames stacked input frames and
+ * targets, then run one SGD-momentum step (train_bunch_single, BP_GPU.cu:484-673) per
+ * consecutive full bunch; the partial last bunch is ignored (:315-318).  Synchronous with
+ * respect to `in`/`targ`. */
+int bp_train_chunk(bp_handle *h, int n_frames, const float *in, const float *targ);
+
+/* BP_GPU::CrossValid (BP_GPU.cu:408-479) + cv_bunch_single (:676-773): inference forward
+ * (weights scaled by keep when dropoutflag==1), partial bunch processed, returns the SUM of
+ * squared errors accumulated in fp32 in frame-major / bin-minor order (:458-467). */
+int bp_cv_chunk(bp_handle *h, int n_frames, const float *in, const float *targ,
+                float *sq_err_sum);
+
+/* cv_bunch_single (BP_GPU.cu:676-773) exposed for parity tests and batch enhancement:
+ * out[n_frames][sL] = network(in) with CV semantics. */
+int bp_forward(bp_handle *h, int n_frames, const float *in, float *out);
+
+/* BP_GPU::returnWeights (BP_GPU.cu:910-923). */
+int bp_get_weights(bp_handle *h, float *const *weights, float *const *bias);
+/* Momentum state (delta_weights/delta_bias, BP_WorkSpace BP_GPU.h:35-36); the reference never
+ * downloads it -- provided for parity tests and checkpointing. */
+int bp_get_deltas(bp_handle *h, float *const *delta_weights, float *const *delta_bias);
+
+/* ------------------------------------------------------------------------------------
+ * Resident-chunk interface: the same step as bp_train_chunk, split so that a caller who
+ * already has the chunk in device memory (benchmarks, on-device data producers) can drive
+ * bunches without the host upload.  bp_upload_chunk = the H2D part of BP_GPU::train
+ * (BP_GPU.cu:269-277); bp_train_resident = the bunch loop (:294-326) over frames
+ * [first_frame, first_frame + n_frames) of the resident chunk.  Asynchronous: returns after
+ * enqueueing; bp_sync waits. */
+int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, const float *targ);
+int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed); /* N(0,1) in/targ on device */
+int bp_train_resident(bp_handle *h, int first_frame, int n_frames);
+int bp_sync(bp_handle *h);
+
+/* ------------------------------------------------------------------------------------
+ * Data-parallel split of train_bunch_single (the reference's dead train_bunch_multi,
+ * BP_GPU.cu:775-908, is the semantics donor): gradients of one local bunch are written to a
+ * flat fp32 device buffer [W_1 | b_1 | W_2 | b_2 ...] (padded layout, see bp_grad_layout),
+ * the caller sums that buffer over ranks (RCCL all-reduce), then bp_apply_update runs
+ * kernUpdatedelta + kernAccSum (DevFunc.cu:313-318, 270-277) with n = global_bunchsize. */
+int bp_grads_resident(bp_handle *h, int first_frame);            /* one local bunch          */
+int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats);
+/* Adopt caller-owned device memory (e.g. a tensor the communication library already knows) as
+ * the flat gradient buffer; n_floats must equal the size bp_grad_buffer reports.  The caller
+ * keeps ownership and must keep it alive until bp_destroy. */
+int bp_use_grad_buffer(bp_handle *h, void *device_ptr, size_t n_floats);
+int bp_grad_floats(bp_handle *h, size_t *n_floats);
+int bp_apply_update(bp_handle *h);
+/* Per-layer view of the flat buffer: offset/count (floats) of layer l's [W|b] segment. */
+int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *count);
+/* Run the device work of this handle on an externally owned hipStream_t (passed as void*),
+ * e.g. the stream a communication library orders against.  NULL restores the private stream. */
+int bp_set_stream(bp_handle *h, void *hip_stream);
+
+/* Timing of the dominant kernels for roofline reporting: average duration (ms) of the last
+ * bp_train_resident call's whole bunch loop measured with HIP events on the handle's stream. */
+int bp_last_train_ms(bp_handle *h, float *ms, int *bunches);
+/* Time `iters` launches of one kernel of the step in isolation (HIP events on the handle's
+ * stream).  which: 0 fwd hidden GEMM(layer 2), 1 dgrad hidden, 2 wgrad+update hidden,
+ * 3 fwd layer 1, 4 fwd output layer, 5 wgrad+update layer 1.  Returns average ms. */
+int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BP_C_API_H */

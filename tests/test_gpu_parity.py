@@ -1,0 +1,157 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes), against the
+oracle on the same seeded inputs and against the committed golden fixtures.
+Tolerance: 1e-4 relative (BASELINE.json north_star), max|a-ref| / max|ref| per tensor."""
+import numpy as np
+import pytest
+
+from util import TOL, golden_cases, load_golden, relerr
+
+from oracle import bp_numpy as N
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(pkg, c_ls, B, W, b, **kw):
+    return pkg.BP_GPU(1, len(c_ls), c_ls, B, kw.pop("lr", 1.0), kw.pop("m", 0.5), kw.pop("wc", 0.0), W, b,
+                      max_chunk_frames=kw.pop("cap", 8 * B), **kw)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_no_dropout_or_cv(pkg, name):
+    """Training steps (cases without dropout) and the CV forward vs the fp64 goldens."""
+    c = load_golden(name)
+    kw = dict(lr=c["lr"], m=c["m"], wc=c["wc"], activation=c["act"], momentum_rule=c["rule"])
+    if c["has_drop"]:
+        kw.update(dropoutflag=1, visible_omit=c["drop"][0], hid_omit=c["drop"][1])
+    g = _mk(pkg, c["ls"], c["B"], c["W"], c["b"], **kw)
+    out = g.forward(c["xs"][0])
+    assert relerr(out, c["cv_out"]) < TOL
+    sq = g.CrossValid(c["B"], c["xs"][0], c["ts"][0])
+    assert abs(sq - c["cv_sqerr"]) < TOL * abs(c["cv_sqerr"])
+    if not c["has_drop"]:
+        x = np.concatenate(c["xs"]); t = np.concatenate(c["ts"])
+        g.train(x.shape[0], x, t)
+        w, b = g.get_weights()
+        for l in range(1, c["L"]):
+            assert relerr(w[l], c["Wf"][l]) < TOL, (name, l)
+            assert relerr(b[l], c["bf"][l]) < TOL, (name, l)
+    g.close()
+
+
+CASES = [
+    # layersizes, B, n_bunches, activation, rule, wc, dropout
+    ([12, 7, 5, 3], 4, 3, 0, 0, 0.0, False),
+    ([257, 512, 257], 128, 3, 1, 1, 0.0, False),                 # C1 shape (Sigmoid, classic)
+    ([1548, 256, 192, 129], 64, 2, 0, 0, 0.001, True),           # shipped 129-bin NAT width, small hidden
+    ([257 * 11, 320, 257], 96, 2, 0, 0, 0.0, True),              # C2 input width, B not a multiple of 64
+    ([70, 65, 130, 33], 12, 3, 1, 0, 0.01, True),                # nothing aligned
+    ([100, 2048, 2048, 40], 256, 2, 0, 0, 0.0, True),            # full-size hidden GEMMs
+]
+
+
+@pytest.mark.parametrize("ls,B,nb,act,rule,wc,drop", CASES)
+def test_train_matches_oracle(pkg, oracle_mod, ls, B, nb, act, rule, wc, drop):
+    W, b = N.glorot_net(ls, seed=5, beta=1.0)
+    rng = np.random.default_rng(17)
+    b = [None] + [rng.normal(size=ls[l]).astype(np.float32) * 0.1 for l in range(1, len(ls))]
+    n = nb * B + (B // 2)                                         # trailing partial bunch must be ignored
+    x = rng.normal(size=(n, ls[0])).astype(np.float32)
+    t = rng.normal(size=(n, ls[-1])).astype(np.float32)
+    kw = dict(activation=act, momentum_rule=rule)
+    if drop:
+        kw.update(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=99)
+    g = _mk(pkg, ls, B, W, b, lr=1.0, m=0.5, wc=wc, **kw)
+    o = oracle_mod.Oracle(ls, B, 1.0, 0.5, wc, W, b, **kw)
+    g.train(n, x, t)
+    assert o.train(x, t) == nb
+    w, bb = g.get_weights()
+    dw, dbb = g.get_deltas()
+    for l in range(1, len(ls)):
+        assert relerr(w[l], o.W[l]) < TOL, ("W", l)
+        assert relerr(bb[l], o.b[l]) < TOL, ("b", l)
+        assert relerr(dw[l], o.dW[l]) < TOL, ("dW", l)
+        assert relerr(dbb[l], o.db[l]) < TOL, ("db", l)
+    # CV with keep-scaled weights on the trained net, partial bunch included
+    cg, co = g.CrossValid(n, x, t), o.crossvalid(x, t)
+    assert abs(cg - co) < TOL * abs(co)
+    assert relerr(g.forward(x[:B + 3]), o.forward(x[:B + 3])) < TOL
+    g.close()
+
+
+def test_dropout_mask_is_the_oracle_philox_stream(pkg, oracle_mod):
+    """With lr=0 nothing moves, so check the mask through its effect: train 1 step with weights
+    that make layer-1 outputs strictly positive, then compare W after the step bit-pattern-wise
+    for which hidden units were dropped (zero gradient rows)."""
+    ls, B = [8, 64, 4], 32
+    rng = np.random.default_rng(1)
+    W = [None, np.abs(rng.normal(size=(8, 64))).astype(np.float32), rng.normal(size=(64, 4)).astype(np.float32)]
+    b = [None, np.ones(64, np.float32), np.zeros(4, np.float32)]
+    x = np.abs(rng.normal(size=(B, 8))).astype(np.float32)
+    t = rng.normal(size=(B, 4)).astype(np.float32)
+    kw = dict(dropoutflag=1, visible_omit=0.0, hid_omit=0.5, seed=4242)
+    g = _mk(pkg, ls, B, W, b, **kw)
+    o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, **kw)
+    g.train(B, x, t); o.train(x, t)
+    w, _ = g.get_weights()
+    assert relerr(w[2], o.W[2]) < TOL and relerr(w[1], o.W[1]) < TOL
+    g.close()
+
+
+def test_dp_split_equals_fused_step(pkg, oracle_mod):
+    """bp_grads_resident + bp_apply_update (the data-parallel split) == the fused single-device
+    step; and with global_bunchsize = 2*B the result equals the oracle's shard semantics."""
+    ls, B = [96, 128, 64, 20], 32
+    W, b = N.glorot_net(ls, seed=9, beta=1.0)
+    rng = np.random.default_rng(2)
+    x = rng.normal(size=(2 * B, ls[0])).astype(np.float32)
+    t = rng.normal(size=(2 * B, ls[-1])).astype(np.float32)
+    a = _mk(pkg, ls, B, W, b)
+    a.train(2 * B, x, t)
+    wa, ba = a.get_weights()
+    s = _mk(pkg, ls, B, W, b)
+    s.upload_chunk(x, t)
+    for i in range(2):
+        s.grads_resident(i * B); s.apply_update()
+    ws, bs = s.get_weights()
+    for l in range(1, len(ls)):
+        assert relerr(ws[l], wa[l]) < 1e-6 and relerr(bs[l], ba[l]) < 1e-6
+    a.close(); s.close()
+    # two "ranks" on one GPU: shard gradients summed on the host == oracle on the global bunch
+    Bg = 2 * B
+    r0 = _mk(pkg, ls, B, W, b, global_bunchsize=Bg, rank_frame_offset=0, gpu_used=2)
+    r1 = _mk(pkg, ls, B, W, b, global_bunchsize=Bg, rank_frame_offset=B, gpu_used=2)
+    r0.upload_chunk(x[:B], t[:B]); r1.upload_chunk(x[B:], t[B:])
+    r0.grads_resident(0); r1.grads_resident(0)
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    p0, n0 = r0.grad_buffer(); p1, n1 = r1.grad_buffer()
+    assert n0 == n1
+    # sum through host memory (stand-in for the RCCL all-reduce in this 1-GPU test)
+    hip = C.CDLL("libamdhip64.so")
+    h0 = np.empty(n0, np.float32); h1 = np.empty(n0, np.float32)
+    r0.sync(); r1.sync()
+    assert hip.hipMemcpy(h0.ctypes.data_as(C.c_void_p), C.c_void_p(p0), C.c_size_t(n0 * 4), 2) == 0
+    assert hip.hipMemcpy(h1.ctypes.data_as(C.c_void_p), C.c_void_p(p1), C.c_size_t(n0 * 4), 2) == 0
+    hs = h0 + h1
+    for r, p in ((r0, p0), (r1, p1)):
+        assert hip.hipMemcpy(C.c_void_p(p), hs.ctypes.data_as(C.c_void_p), C.c_size_t(n0 * 4), 1) == 0
+        r.apply_update()
+    o = oracle_mod.Oracle(ls, Bg, 1.0, 0.5, 0.0, W, b)
+    o.train(x, t)
+    for r in (r0, r1):
+        w, bb = r.get_weights()
+        for l in range(1, len(ls)):
+            assert relerr(w[l], o.W[l]) < TOL and relerr(bb[l], o.b[l]) < TOL
+        r.close()
+
+
+def test_errors_are_reported_not_swallowed(pkg):
+    W, b = N.glorot_net([8, 4, 2], seed=1)
+    with pytest.raises(pkg.BPError):
+        pkg.BP_GPU(1, 3, [8, 4, 2], 4, 1.0, 0.5, 0.0, W, b, device=99)
+    g = pkg.BP_GPU(1, 3, [8, 4, 2], 4, 1.0, 0.5, 0.0, W, b, max_chunk_frames=8)
+    with pytest.raises(pkg.BPError):
+        g.train(16, np.zeros((16, 8), np.float32), np.zeros((16, 2), np.float32))   # exceeds chunk capacity
+    with pytest.raises(pkg.BPError):
+        g.train_resident(0, 4)                                                        # nothing resident
+    g.close()

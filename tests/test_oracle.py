@@ -1,0 +1,116 @@
+"""CPU tests (-m "not gpu"): pin the C oracle (oracle/bp_oracle.c) against the committed
+golden fixtures (numpy fp64 restatement), against torch autograd of the equivalent loss, and
+check the host-visible pieces of its dropout stream."""
+import numpy as np
+import pytest
+
+from util import TOL, golden_cases, load_golden, relerr
+
+from oracle import bp_numpy as N
+
+
+@pytest.mark.parametrize("name", golden_cases())
+@pytest.mark.parametrize("acc_double", [False, True])
+def test_oracle_matches_golden(oracle_mod, name, acc_double):
+    c = load_golden(name)
+    o = oracle_mod.Oracle(c["ls"], c["B"], lrate=c["lr"], momentum=c["m"], weightcost=c["wc"], weights=c["W"],
+                          bias=c["b"], activation=c["act"], momentum_rule=c["rule"], acc_double=acc_double,
+                          dropoutflag=1 if c["has_drop"] else 0, visible_omit=c["drop"][0], hid_omit=c["drop"][1])
+    gw, gb, ys, out = o.grads(c["xs"][0], c["ts"][0], None if c["masks"] is None else c["masks"][0])
+    assert relerr(out, c["out0"]) < 1e-5
+    for l in range(1, c["L"]):
+        if c["gw"][l] is not None:
+            assert relerr(gw[l], c["gw"][l]) < 1e-5
+        assert relerr(gb[l], c["gb"][l]) < 1e-5
+    for s in range(c["steps"]):
+        o.train_bunch(c["xs"][s], c["ts"][s], masks=None if c["masks"] is None else c["masks"][s], gen_masks=False)
+    for l in range(1, c["L"]):
+        assert relerr(o.W[l], c["Wf"][l]) < 1e-5
+        assert relerr(o.b[l], c["bf"][l]) < 1e-5
+    # CV forward with keep-scaled weights + summed squared error (BP_GPU.cu:408-479)
+    o2 = oracle_mod.Oracle(c["ls"], max(1, c["B"] // 2 + 1), weights=c["W"], bias=c["b"], activation=c["act"],
+                           dropoutflag=1 if c["has_drop"] else 0, visible_omit=c["drop"][0], hid_omit=c["drop"][1])
+    assert relerr(o2.forward(c["xs"][0]), c["cv_out"]) < 1e-5
+    assert abs(o2.crossvalid(c["xs"][0], c["ts"][0]) - c["cv_sqerr"]) < 1e-4 * abs(c["cv_sqerr"])
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_oracle_gradient_is_autograd_of_mse(oracle_mod, act):
+    """Steps 4+6 of SURVEY App. A are the exact gradient of (1/B) sum (out-t)^2."""
+    torch = pytest.importorskip("torch")
+    ls, B = [20, 16, 9, 6], 10
+    W, b = N.glorot_net(ls, seed=11, beta=2.0)
+    rng = np.random.default_rng(3)
+    b = [None] + [rng.normal(size=ls[l]).astype(np.float32) * 0.2 for l in range(1, len(ls))]
+    x = rng.normal(size=(B, ls[0])).astype(np.float32)
+    t = rng.normal(size=(B, ls[-1])).astype(np.float32)
+    o = oracle_mod.Oracle(ls, B, weights=W, bias=b, activation=act, acc_double=True)
+    gw, gb, _, out = o.grads(x, t)
+    tw = [None] + [torch.tensor(W[l], dtype=torch.float64, requires_grad=True) for l in range(1, len(ls))]
+    tb = [None] + [torch.tensor(b[l], dtype=torch.float64, requires_grad=True) for l in range(1, len(ls))]
+    y = torch.tensor(x, dtype=torch.float64)
+    for l in range(1, len(ls)):
+        y = y @ tw[l] + tb[l]
+        if l != len(ls) - 1:
+            y = torch.relu(y) if act == 0 else torch.sigmoid(y)
+    loss = ((y - torch.tensor(t, dtype=torch.float64)) ** 2).sum() / B
+    loss.backward()
+    assert relerr(out, y.detach().numpy()) < 1e-6
+    for l in range(1, len(ls)):
+        assert relerr(gw[l], tw[l].grad.numpy()) < 1e-5
+        assert relerr(gb[l], tb[l].grad.numpy()) < 1e-5
+
+
+def test_partial_last_bunch_is_dropped(oracle_mod):
+    """BP_GPU.cu:315-318: train() ignores a trailing partial bunch; CV keeps it (:450-453)."""
+    ls, B = [6, 5, 4], 4
+    W, b = N.glorot_net(ls, seed=2, beta=1.0)
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(11, 6)).astype(np.float32)
+    t = rng.normal(size=(11, 4)).astype(np.float32)
+    a = oracle_mod.Oracle(ls, B, weights=W, bias=b)
+    c = oracle_mod.Oracle(ls, B, weights=W, bias=b)
+    assert a.train(x, t) == 2
+    assert c.train(x[:8], t[:8]) == 2
+    for l in (1, 2):
+        assert np.array_equal(a.W[l], c.W[l])
+    full = oracle_mod.Oracle(ls, B, weights=W, bias=b)
+    assert abs(full.crossvalid(x, t) - ((full.forward(x).astype(np.float64) - t) ** 2).sum()) < 1e-3
+
+
+def test_philox_mask_statistics_and_keying(oracle_mod):
+    """u in (0,1], P(drop) = p; masks differ per step/layer, and are a function of the GLOBAL
+    frame index (data-parallel invariance)."""
+    ls = [64, 48, 8]
+    W, b = N.glorot_net(ls, seed=1)
+    o = oracle_mod.Oracle(ls, 256, weights=W, bias=b, dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=1234)
+    m0 = o.fill_mask(0, 0, 256)
+    m1 = o.fill_mask(0, 1, 256)
+    assert abs(m0.mean() - 0.1) < 0.01 and abs(m1.mean() - 0.2) < 0.015
+    assert not np.array_equal(m0, o.fill_mask(1, 0, 256))
+    # shard [64,128) of the global bunch == rows 64..127 of the full mask
+    assert np.array_equal(o.fill_mask(0, 0, 64, gframe0=64), m0[64:128])
+    assert oracle_mod.drop_threshold(0.0) == 0 and oracle_mod.drop_threshold(1.0) == 0xFFFFFFFF
+    assert oracle_mod.drop_threshold(0.5) == 0x80000000
+
+
+def test_dp_shards_sum_to_single_device(oracle_mod):
+    """Gradient of the global bunch == sum of shard gradients computed with scale 2/B_global
+    (the semantics the RCCL path implements)."""
+    ls, Bg, G = [10, 12, 5], 16, 4
+    W, b = N.glorot_net(ls, seed=4, beta=2.0)
+    rng = np.random.default_rng(8)
+    x = rng.normal(size=(Bg, 10)).astype(np.float32)
+    t = rng.normal(size=(Bg, 5)).astype(np.float32)
+    o = oracle_mod.Oracle(ls, Bg, weights=W, bias=b, acc_double=True)
+    gw, gb, _, _ = o.grads(x, t)
+    sw = [None, 0, 0]
+    sb = [None, 0, 0]
+    for r in range(G):
+        sl = slice(r * Bg // G, (r + 1) * Bg // G)
+        w_, b_, _, _ = o.grads(x[sl], t[sl], scale_frames=Bg)
+        for l in (1, 2):
+            sw[l] = sw[l] + w_[l].astype(np.float64)
+            sb[l] = sb[l] + b_[l].astype(np.float64)
+    for l in (1, 2):
+        assert relerr(sw[l], gw[l]) < 1e-6 and relerr(sb[l], gb[l]) < 1e-6
