@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "bp_last_error", "bp_abi_version", "bp_build_target", "bp_create", "bp_destroy", "bp_train_chunk",
     "bp_cv_chunk", "bp_forward", "bp_get_weights", "bp_get_deltas", "bp_upload_chunk",
     "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident", "bp_grad_buffer",
-    "bp_apply_update", "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
+    "bp_apply_update", "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
 ]
 
 
@@ -83,6 +83,8 @@ def load_library(path=None):
     lib.bp_apply_update.argtypes = [hp]
     lib.bp_use_grad_buffer.argtypes = [hp, C.c_void_p, C.c_size_t]
     lib.bp_grad_floats.argtypes = [hp, C.POINTER(C.c_size_t)]
+    lib.bp_read_grads.argtypes = [hp, fp, C.c_size_t]
+    lib.bp_write_grads.argtypes = [hp, fp, C.c_size_t]
     lib.bp_grad_layout.argtypes = [hp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.bp_set_stream.argtypes = [hp, C.c_void_p]
     lib.bp_last_train_ms.argtypes = [hp, fp, C.POINTER(C.c_int)]
@@ -231,6 +233,15 @@ class BP_GPU(object):
 
     def use_grad_buffer(self, device_ptr, n_floats):
         self._check(self._lib.bp_use_grad_buffer(self._h, C.c_void_p(device_ptr), int(n_floats)))
+
+    def read_grads(self):
+        g = np.empty(self.grad_floats(), np.float32)
+        self._check(self._lib.bp_read_grads(self._h, _fp(g), g.size))
+        return g
+
+    def write_grads(self, g):
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        self._check(self._lib.bp_write_grads(self._h, _fp(g), g.size))
 
     def grad_layout(self, layer):
         o, c = C.c_size_t(), C.c_size_t()

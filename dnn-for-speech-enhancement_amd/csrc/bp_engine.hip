@@ -60,8 +60,12 @@ extern "C" const char *bp_last_error(void) { return g_err.c_str(); }
 extern "C" int bp_abi_version(void) { return 1; }
 extern "C" const char *bp_build_target(void) { return "gfx950"; }
 
+// Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM
+// loaders (no predicates, see GemmArgs) stay inside the allocation.
+static const size_t SLACK = 4096;
 static int dev_alloc(bp_handle *h, float **p, size_t n_floats)
 {
+    n_floats += SLACK;
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, n_floats * sizeof(float));
     if (e != hipSuccess) return fail(BP_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
@@ -130,10 +134,12 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     HK(hipEventCreate(&h->ev0));
     HK(hipEventCreate(&h->ev1));
     const int L = h->L;
-    CK(dev_alloc(h, &h->in, (size_t)h->cap * h->ld[0]));
-    if (cfg->dropoutflag == 1 && h->th_vis) CK(dev_alloc(h, &h->in_drop, (size_t)h->cap * h->ld[0]));
-    CK(dev_alloc(h, &h->targ, (size_t)h->cap * h->ld[L - 1]));
-    CK(dev_alloc(h, &h->out_dev, (size_t)h->B * h->ld[L - 1]));
+    const size_t Bp = (size_t)((h->B + 63) & ~63);             // bunch rows rounded up to a whole tile
+    const size_t capp = (size_t)h->cap + 64;
+    CK(dev_alloc(h, &h->in, capp * h->ld[0]));
+    if (cfg->dropoutflag == 1 && h->th_vis) CK(dev_alloc(h, &h->in_drop, capp * h->ld[0]));
+    CK(dev_alloc(h, &h->targ, capp * h->ld[L - 1]));
+    CK(dev_alloc(h, &h->out_dev, Bp * h->ld[L - 1]));
     HK(hipHostMalloc((void **)&h->host_out, (size_t)h->B * h->ld[L - 1] * sizeof(float)));
     size_t goff = 0;
     for (int l = 1; l < L; ++l) {
@@ -142,8 +148,8 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
         CK(dev_alloc(h, &h->dW[l], nw));
         CK(dev_alloc(h, &h->b[l], h->ld[l]));
         CK(dev_alloc(h, &h->db[l], h->ld[l]));
-        CK(dev_alloc(h, &h->y[l], (size_t)h->B * h->ld[l]));
-        CK(dev_alloc(h, &h->dx[l], (size_t)h->B * h->ld[l]));
+        CK(dev_alloc(h, &h->y[l], Bp * h->ld[l]));       // rows >= B stay zero (never stored)
+        CK(dev_alloc(h, &h->dx[l], Bp * h->ld[l]));      // rows >= B stay zero: k-tail of wgrad
         h->g_off[l] = goff; h->g_cnt[l] = nw + h->ld[l]; goff += h->g_cnt[l];
     }
     h->grad_floats = goff;
@@ -179,13 +185,13 @@ extern "C" int bp_sync(bp_handle *h)
 }
 
 // ------------------------------------------------------------------ launches
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI>
-static hipError_t launch(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N)
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1>
+static hipError_t launch(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N, int dyn_lds = 0)
 {
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
-    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, st,
-                       g, e);
+    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>), dim3(g.tiles_m * g.tiles_n), dim3(256),
+                       dyn_lds, st, g, e);
     return hipGetLastError();
 }
 
@@ -205,7 +211,6 @@ static hipError_t launch_fwd(bp_handle *h, int l, int M, const float *y_prev, co
     const int L = h->L, prev = h->ld[l - 1], cur = h->ld[l];
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = y_prev; g.lda = prev; g.B = h->W[l]; g.ldb = cur; g.K = prev;
-    g.a_row_limit = M; g.a_col_limit = prev; g.b_row_limit = prev; g.b_col_limit = cur;
     EpiArgs e = epi_zero();
     e.m_limit = M; e.n_limit = cur; e.n_true = h->s[l]; e.bias = h->b[l]; e.alpha = alpha; e.act = h->cfg.activation;
     if (l != L - 1) {
@@ -229,7 +234,6 @@ static hipError_t launch_dgrad(bp_handle *h, int l, int M)
     const int prev = h->ld[l - 1], cur = h->ld[l];
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = h->dx[l]; g.lda = cur; g.B = h->W[l]; g.ldb = cur; g.K = cur;
-    g.a_row_limit = M; g.a_col_limit = cur; g.b_row_limit = prev; g.b_col_limit = cur;
     EpiArgs e = epi_zero();
     e.C = h->dx[l - 1]; e.ldc = prev; e.m_limit = M; e.n_limit = prev; e.n_true = h->s[l - 1];
     e.aux = h->y[l - 1]; e.ldaux = prev; e.act = h->cfg.activation;
@@ -244,7 +248,6 @@ static hipError_t launch_wgrad(bp_handle *h, int l, int M, const float *y_prev, 
     const int prev = h->ld[l - 1], cur = h->ld[l];
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = y_prev; g.lda = prev; g.B = h->dx[l]; g.ldb = cur; g.K = M;
-    g.a_row_limit = M; g.a_col_limit = prev; g.b_row_limit = M; g.b_col_limit = cur;
     EpiArgs e = epi_zero();
     e.ldc = cur; e.m_limit = prev; e.n_limit = cur; e.n_true = h->s[l];
     if (fused) {
@@ -403,6 +406,28 @@ extern "C" int bp_grad_floats(bp_handle *h, size_t *n_floats)
 {
     if (!h || !n_floats) return fail(BP_ERR_ARG, "null argument");
     *n_floats = h->grad_floats;
+    return BP_OK;
+}
+
+extern "C" int bp_read_grads(bp_handle *h, float *host_dst, size_t n_floats)
+{
+    if (!h || !host_dst) return fail(BP_ERR_ARG, "null argument");
+    if (!h->grad) return fail(BP_ERR_STATE, "bp_read_grads: no gradients (call bp_grads_resident first)");
+    if (n_floats != h->grad_floats) return fail(BP_ERR_ARG, "bp_read_grads: size must equal bp_grad_floats");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(host_dst, h->grad, n_floats * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return BP_OK;
+}
+
+extern "C" int bp_write_grads(bp_handle *h, const float *host_src, size_t n_floats)
+{
+    if (!h || !host_src) return fail(BP_ERR_ARG, "null argument");
+    if (n_floats != h->grad_floats) return fail(BP_ERR_ARG, "bp_write_grads: size must equal bp_grad_floats");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
+    HIPCHK(hipMemcpyAsync(h->grad, host_src, n_floats * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return BP_OK;
 }
 

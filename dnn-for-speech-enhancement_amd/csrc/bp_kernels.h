@@ -12,23 +12,39 @@
 // (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) is a conflict-free ds_read_b32 of 32
 // consecutive dwords per half-wave.  k-contiguous global operands are transposed on the way
 // in (float4 global load -> 4 x ds_write_b32, odd row stride => conflict-free); m/n-contiguous
-// operands go in with ds_write_b128.  Register-staged double buffering: global loads of
-// k-tile t+1 are in flight while tile t is multiplied; one barrier per k-tile.
+// operands go in with ds_write_b128.  Register-staged software pipeline: global loads of k-tiles
+// t+1..t+PF are in flight while tile t is multiplied; LDS double buffered, one barrier per k-tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+#include <utility>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(std::forward<F>(f));
+    }
+}
 
 enum { EPI_FWD_HIDDEN = 0, EPI_FWD_OUT = 1, EPI_DGRAD = 2, EPI_WGRAD_UPDATE = 3, EPI_WGRAD_STORE = 4 };
 
+// The k-loop loads carry NO predicates (a predicated load makes hipcc drain vmcnt at the top of
+// every iteration, which serialises the prefetch).  Contract with the caller instead:
+//   * every operand buffer is readable for whole tiles (rows rounded up to the tile, one extra
+//     row of slack), so tile reads never leave the allocation;
+//   * rows/columns past the true extents either hold zeros (layer-width padding; dEdX rows past
+//     the bunch, which zero the k-tail of wgrad) or only feed accumulator rows that the
+//     epilogue never stores (frames past the bunch in fwd/dgrad).
 struct GemmArgs {
     const float *A, *B;
     int lda, ldb;            // leading dimensions (floats)
     int K;                   // reduction extent actually looped (rounded up to BK inside)
-    int a_row_limit;         // rows of A's non-contiguous index that exist (m for [m][k], k for [k][m])
-    int b_row_limit;         // same for B (n for [n][k], k for [k][n])
-    int a_col_limit, b_col_limit; // extent of the contiguous index (padded leading extent)
     int tiles_m, tiles_n;
 };
 
@@ -78,7 +94,8 @@ __device__ __forceinline__ float act_bwd(int act, float y)
 // ------------------------------------------------------------------ epilogue of one 32x32 block
 // C/D layout of v_mfma_f32_32x32x2_f32: lane l, reg r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
 template <int EPI>
-__device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb, const f32x16 &acc, int lane)
+__device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb, const f32x16 &acc, int lane,
+                                               const f32x16 &wpre, const f32x16 &dpre)
 {
     const int n = nb + (lane & 31);
     const int rbase = mb + 4 * (lane >> 5);
@@ -134,8 +151,8 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             if (m < e.m_limit) {
                 const size_t i = (size_t)m * e.ldc + n;
-                const float w = e.C[i];
-                const float d = e.mom * e.aux2[i] - e.c1 * (acc[r] / e.ndiv + e.wc * w);  // kernUpdatedelta
+                const float w = wpre[r];
+                const float d = e.mom * dpre[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);    // kernUpdatedelta
                 e.aux2[i] = d;
                 e.C[i] = d + 1.0f * w;                                                     // kernAccSum
             }
@@ -150,23 +167,198 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
 }
 
 // ------------------------------------------------------------------ the GEMM
+// Register image of one k-tile of both operands (global -> registers -> LDS staging).
+template <int NVA, int NVB>
+struct TileRegs { float4 a[NVA]; float4 b[NVB]; };
+
 // BM x BN x BK workgroup tile, 4 waves arranged WM x WN x KS (KS = 4/(WM*WN) splits each
 // k-tile between wave groups; partial sums meet in LDS before the epilogue).
 // A_KC: A is [m][k] in memory (k contiguous) else [k][m]; B_KC: B is [n][k] else [k][n].
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e)
-{
-    constexpr int KS = 4 / (WM * WN);
-    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+// PF = k-tiles in flight in registers beyond the one being staged into LDS (1..2).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF>
+struct GemmCfg {
+    static constexpr int KS = 4 / (WM * WN);
+    static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    static constexpr int LDA_S = A_KC ? BM + 1 : BM;
+    static constexpr int LDB_S = B_KC ? BN + 1 : BN;
+    static constexpr int A_STAGE = (BK * LDA_S + 3) & ~3, B_STAGE = (BK * LDB_S + 3) & ~3;
+    static constexpr int NVA = BM * BK / 4 / 256, NVB = BN * BK / 4 / 256;
+    static constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;     // lanes per 128-byte row segment
+    static constexpr bool BIASG = (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE);
     static_assert(WM * WN * KS == 4 && TM >= 1 && TN >= 1, "wave layout");
     static_assert(BK % (2 * KS) == 0 && BK % 4 == 0, "BK");
-    constexpr int LDA_S = A_KC ? BM + 1 : BM;
-    constexpr int LDB_S = B_KC ? BN + 1 : BN;
-    constexpr int A_STAGE = (BK * LDA_S + 3) & ~3, B_STAGE = (BK * LDB_S + 3) & ~3;
-    constexpr int NVA = BM * BK / 4 / 256, NVB = BN * BK / 4 / 256;
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
+    static_assert(PF >= 1 && PF <= 2, "PF (k-tiles in flight beyond the one being staged)");
+    using Regs = TileRegs<NVA, NVB>;
+
+    // Addressing: uniform tile base (SGPR) + per-thread 32-bit offset that never changes, so a
+    // load is one instruction and the k-advance is scalar arithmetic.
+    struct Offs { int a[NVA]; int b[NVB]; };
+    static __device__ __forceinline__ void make_offs(Offs &o, const GemmArgs &g, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int f = tid + i * 256;
+            if constexpr (A_KC) {
+                const int l8 = f % LPS, seg = f / LPS, row = seg % BM, k4 = (seg / BM) * LPS + l8;
+                o.a[i] = row * g.lda + k4 * 4;
+            } else {
+                const int c4 = f % (BM / 4), k = f / (BM / 4);
+                o.a[i] = k * g.lda + c4 * 4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int f = tid + i * 256;
+            if constexpr (B_KC) {
+                const int l8 = f % LPS, seg = f / LPS, row = seg % BN, k4 = (seg / BN) * LPS + l8;
+                o.b[i] = row * g.ldb + k4 * 4;
+            } else {
+                const int c4 = f % (BN / 4), k = f / (BN / 4);
+                o.b[i] = k * g.ldb + c4 * 4;
+            }
+        }
+    }
+    // uniform base of k-tile k0 for each operand
+    static __device__ __forceinline__ const float *base_a(const GemmArgs &g, int m0, int k0)
+    {
+        return A_KC ? g.A + (size_t)m0 * g.lda + k0 : g.A + (size_t)k0 * g.lda + m0;
+    }
+    static __device__ __forceinline__ const float *base_b(const GemmArgs &g, int n0, int k0)
+    {
+        return B_KC ? g.B + (size_t)n0 * g.ldb + k0 : g.B + (size_t)k0 * g.ldb + n0;
+    }
+    static __device__ __forceinline__ void load_a(Regs &r, int i, const float *pa, const Offs &o)
+    {
+        r.a[i] = *reinterpret_cast<const float4 *>(pa + o.a[i]);
+    }
+    static __device__ __forceinline__ void load_b(Regs &r, int i, const float *pb, const Offs &o)
+    {
+        r.b[i] = *reinterpret_cast<const float4 *>(pb + o.b[i]);
+    }
+    static __device__ __forceinline__ void load(Regs &r, const float *pa, const float *pb, const Offs &o)
+    {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) load_a(r, i, pa, o);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) load_b(r, i, pb, o);
+    }
+
+    // one float4 of the A / B register image -> LDS (k-major, transposing k-contiguous operands)
+    static __device__ __forceinline__ void store_a(const Regs &r, int i, float *As, int tid)
+    {
+        const int f = tid + i * 256;
+        const float4 v = r.a[i];          // (a local copy keeps the register set out of scratch)
+        if constexpr (A_KC) {
+            const int l8 = f % LPS, seg = f / LPS, row = seg % BM, k4 = (seg / BM) * LPS + l8;
+            As[(k4 * 4 + 0) * LDA_S + row] = v.x; As[(k4 * 4 + 1) * LDA_S + row] = v.y;
+            As[(k4 * 4 + 2) * LDA_S + row] = v.z; As[(k4 * 4 + 3) * LDA_S + row] = v.w;
+        } else {
+            const int c4 = f % (BM / 4), k = f / (BM / 4);
+            *reinterpret_cast<float4 *>(As + k * LDA_S + c4 * 4) = v;
+        }
+    }
+    static __device__ __forceinline__ void store_b(const Regs &r, int i, float *Bs, int tid, float4 &bsum)
+    {
+        const int f = tid + i * 256;
+        const float4 v = r.b[i];
+        if constexpr (B_KC) {
+            const int l8 = f % LPS, seg = f / LPS, row = seg % BN, k4 = (seg / BN) * LPS + l8;
+            Bs[(k4 * 4 + 0) * LDB_S + row] = v.x; Bs[(k4 * 4 + 1) * LDB_S + row] = v.y;
+            Bs[(k4 * 4 + 2) * LDB_S + row] = v.z; Bs[(k4 * 4 + 3) * LDB_S + row] = v.w;
+        } else {
+            const int c4 = f % (BN / 4), k = f / (BN / 4);
+            *reinterpret_cast<float4 *>(Bs + k * LDB_S + c4 * 4) = v;
+            if constexpr (BIASG) {   // every thread keeps the same 4 columns across k-tiles
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;   // used by m-tile 0 only
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(const Regs &r, float *As, float *Bs, int tid, float4 &bsum)
+    {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) store_a(r, i, As, tid);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) store_b(r, i, Bs, tid, bsum);
+    }
+
+    // One k-tile: multiply the tile resident in LDS stage (As, Bs) into acc (this wave takes
+    // k-range `ks`); between the MFMAs (a) fetch the operand fragments RD steps ahead, (b) issue
+    // the global loads of a later k-tile into register image rl, (c) move the NEXT k-tile
+    // (register image rs) into the other LDS stage.  Everything except the first RD fragment
+    // reads issues while the matrix pipe is busy.  NCH independent accumulator chains
+    // (a single dependent v_mfma_f32_32x32x2_f32 chain only reaches 90 % of the issue rate).
+    static constexpr int NCH = (TM * TN == 1) ? 2 : 1;
+    template <bool DO_STORE, bool DO_LOAD>
+    static __device__ __forceinline__ void step(const float *As, const float *Bs, f32x16 (&acc)[NCH][TM][TN], int ks,
+                                                int a_off, int b_off, int kh, const Regs &rs, float *AsN, float *BsN,
+                                                Regs &rl, const float *pa, const float *pb, const Offs &o, int tid,
+                                                float4 &bsum)
+    {
+        constexpr int NK = BK / KS / 2, NP = NVA + NVB, RD = NK < 4 ? NK : 4;
+        const float *ap = As + (ks * (BK / KS) + kh) * LDA_S + a_off;
+        const float *bp = Bs + (ks * (BK / KS) + kh) * LDB_S + b_off;
+        float av[NK][TM], bv[NK][TN];
+        // hipcc's scheduler otherwise sinks every ds_read next to its MFMA (one exposed LDS latency
+        // per pair), gathers the ds_writes in front of the barrier and the global loads + their
+        // address arithmetic in front of the first MFMA; pin the intended interleave.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < RD; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[s][i] = ap[2 * s * LDA_S + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[s][j] = bp[2 * s * LDB_S + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int pl = 0, ps = 0;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[s % NCH][i][j] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[s % NCH][i][j], 0, 0, 0);
+            if (s + RD < NK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[s + RD][i] = ap[2 * (s + RD) * LDA_S + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[s + RD][j] = bp[2 * (s + RD) * LDB_S + j * 32];
+            }
+            if constexpr (DO_LOAD) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {               // load piece q goes after MFMA step q*NK/NP
+                    if (q == pl && (q * NK) / NP == s) {
+                        if (q < NVA) load_a(rl, q, pa, o); else load_b(rl, q - NVA, pb, o);
+                        ++pl;
+                    }
+                }
+            }
+            if constexpr (DO_STORE) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {               // store piece q: same slots
+                    if (q == ps && (q * NK) / NP == s) {
+                        if (q < NVA) store_a(rs, q, AsN, tid); else store_b(rs, q - NVA, BsN, tid, bsum);
+                        ++ps;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1>
+__global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e)
+{
+    using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
+    using Regs = typename Cfg::Regs;
+    constexpr int KS = Cfg::KS, TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int A_STAGE = Cfg::A_STAGE, B_STAGE = Cfg::B_STAGE, STAGE = A_STAGE + B_STAGE;
+    constexpr bool BIASG = Cfg::BIASG;
     constexpr int RED = (KS > 1) ? (KS - 1) * WM * WN * TM * TN * 16 * 64 : 0;
-    constexpr int SMEM = (2 * (A_STAGE + B_STAGE) > RED) ? 2 * (A_STAGE + B_STAGE) : RED;
+    constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,7 +368,7 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
     // n-tiles so the W / dEdX column panels it streams stay in its private L2.
     int tile_m, tile_n;
     {
-        const int b = blockIdx.x, T = g.tiles_m * g.tiles_n;
+        const int b = blockIdx.x;
         if ((g.tiles_n & 7) == 0) {
             const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3;
             tile_n = xcd * per + j / g.tiles_m;
@@ -185,115 +377,130 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
             tile_m = b % g.tiles_m;
             tile_n = b / g.tiles_m;
         }
-        (void)T;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    float4 ra[NVA], rb[NVB];
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};   // bias-gradient partial sums (wgrad, m-tile 0 only)
-    constexpr bool BIASG = (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE);
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias-gradient partial sums (wgrad; used by m-tile 0)
     const bool do_bias = BIASG && tile_m == 0;
 
-    auto load_tiles = [&](int k0) {
+    constexpr int NCH = Cfg::NCH;
+    f32x16 accs[NCH][TM][TN];
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int f = tid + i * 256;
-            if constexpr (A_KC) {
-                constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;
-                const int l8 = f % LPS, seg = f / LPS, r = seg % BM, k4 = (seg / BM) * LPS + l8;
-                const bool ok = (m0 + r) < g.a_row_limit && (k0 + k4 * 4) < g.a_col_limit;
-                ra[i] = ok ? *reinterpret_cast<const float4 *>(g.A + (size_t)(m0 + r) * g.lda + k0 + k4 * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int c4 = f % (BM / 4), k = f / (BM / 4);
-                const bool ok = (k0 + k) < g.a_row_limit && (m0 + c4 * 4) < g.a_col_limit;
-                ra[i] = ok ? *reinterpret_cast<const float4 *>(g.A + (size_t)(k0 + k) * g.lda + m0 + c4 * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+    for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int f = tid + i * 256;
-            if constexpr (B_KC) {
-                constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;
-                const int l8 = f % LPS, seg = f / LPS, r = seg % BN, k4 = (seg / BN) * LPS + l8;
-                const bool ok = (n0 + r) < g.b_row_limit && (k0 + k4 * 4) < g.b_col_limit;
-                rb[i] = ok ? *reinterpret_cast<const float4 *>(g.B + (size_t)(n0 + r) * g.ldb + k0 + k4 * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const int c4 = f % (BN / 4), k = f / (BN / 4);
-                const bool ok = (k0 + k) < g.b_row_limit && (n0 + c4 * 4) < g.b_col_limit;
-                rb[i] = ok ? *reinterpret_cast<const float4 *>(g.B + (size_t)(k0 + k) * g.ldb + n0 + c4 * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        float *As = smem + buf * (A_STAGE + B_STAGE), *Bs = As + A_STAGE;
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < NVA; ++i) {
-            const int f = tid + i * 256;
-            if constexpr (A_KC) {
-                constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;
-                const int l8 = f % LPS, seg = f / LPS, r = seg % BM, k4 = (seg / BM) * LPS + l8;
-                As[(k4 * 4 + 0) * LDA_S + r] = ra[i].x; As[(k4 * 4 + 1) * LDA_S + r] = ra[i].y;
-                As[(k4 * 4 + 2) * LDA_S + r] = ra[i].z; As[(k4 * 4 + 3) * LDA_S + r] = ra[i].w;
-            } else {
-                const int c4 = f % (BM / 4), k = f / (BM / 4);
-                *reinterpret_cast<float4 *>(As + k * LDA_S + c4 * 4) = ra[i];
-            }
-        }
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < NVB; ++i) {
-            const int f = tid + i * 256;
-            if constexpr (B_KC) {
-                constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;
-                const int l8 = f % LPS, seg = f / LPS, r = seg % BN, k4 = (seg / BN) * LPS + l8;
-                Bs[(k4 * 4 + 0) * LDB_S + r] = rb[i].x; Bs[(k4 * 4 + 1) * LDB_S + r] = rb[i].y;
-                Bs[(k4 * 4 + 2) * LDB_S + r] = rb[i].z; Bs[(k4 * 4 + 3) * LDB_S + r] = rb[i].w;
-            } else {
-                const int c4 = f % (BN / 4), k = f / (BN / 4);
-                *reinterpret_cast<float4 *>(Bs + k * LDB_S + c4 * 4) = rb[i];
-                if constexpr (BIASG) {   // every thread keeps the same 4 columns across k-tiles
-                    if (do_bias) { bsum[0] += rb[i].x; bsum[1] += rb[i].y; bsum[2] += rb[i].z; bsum[3] += rb[i].w; }
-                }
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.0f;
 
     const int nt = (g.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
     const int a_off = wm * TM * 32 + (lane & 31), b_off = wn * TN * 32 + (lane & 31);
     const int kh = lane >> 5;
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) load_tiles((t + 1) * BK);
-        const float *As = smem + buf * (A_STAGE + B_STAGE), *Bs = As + A_STAGE;
-#pragma unroll
-        for (int kk = ks * (BK / KS); kk < (ks + 1) * (BK / KS); kk += 2) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[(kk + kh) * LDA_S + a_off + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[(kk + kh) * LDB_S + b_off + j * 32];
+
+    // W / delta tiles of the fused update are fetched up front so the HBM latency hides under
+    // the k-loop (same lane->element map as the accumulator).
+    f32x16 wpre[TM][TN], dpre[TM][TN];
+    if constexpr (EPI == EPI_WGRAD_UPDATE) {
+        if (ks == 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+                    const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = rbase + (r & 3) + 8 * (r >> 2);
+                        const size_t idx = (size_t)m * e.ldc + n;     // in-bounds by the GemmArgs contract
+                        wpre[i][j][r] = e.C[idx];
+                        dpre[i][j][r] = e.aux2[idx];
+                    }
+                }
         }
-        if (t + 1 < nt) store_tiles(buf ^ 1);
-        __syncthreads();
+    }
+
+    // ---- software pipeline: LDS holds tile t (double buffered), register sets hold tiles
+    // t+1 .. t+PF in flight.  One barrier per k-tile.  Every load in the steady-state loop is
+    // unconditional (past the end the tile index is clamped and the data ignored): a
+    // conditional load turns into a phi + copy and hipcc then waits for it right away.
+    const int last_k0 = (nt - 1) * BK;
+    typename Cfg::Offs offs;
+    Cfg::make_offs(offs, g, tid);
+#define K0_OF(t) (((t) * BK) < last_k0 ? ((t) * BK) : last_k0)
+#define PA(t) Cfg::base_a(g, m0, K0_OF(t))
+#define PB(t) Cfg::base_b(g, n0, K0_OF(t))
+#define AS(buf) (smem + (buf) * STAGE)
+#define BS(buf) (smem + (buf) * STAGE + A_STAGE)
+// multiply stage `buf`; ST: store image RS into the other stage; LD: load tile TL into image RL
+#define STEP(ST, LD, buf, RS, RL, TL)                                                                      \
+    Cfg::template step<ST, LD>(AS(buf), BS(buf), accs, ks, a_off, b_off, kh, RS, AS((buf) ^ 1), BS((buf) ^ 1),    \
+                               RL, PA(TL), PB(TL), offs, tid, bsum)
+    Regs r0, r1, r2;
+    Cfg::load(r0, PA(0), PB(0), offs);
+    Cfg::store(r0, AS(0), BS(0), tid, bsum);
+    Cfg::load(r1, PA(1), PB(1), offs);
+    if constexpr (PF >= 2) Cfg::load(r2, PA(2), PB(2), offs);
+    __syncthreads();
+    // Invariant at the top of iteration t: LDS stage t&1 holds tile t; tile t+1 (and t+2 when
+    // PF == 2) are in flight / landed in registers.  The iteration multiplies tile t and, between
+    // the MFMAs, issues the global loads of tile t+1+PF and moves tile t+1 into the other stage.
+    // The steady-state loops contain no conditionals (a conditional step makes hipcc copy the
+    // accumulators between register ranges every iteration); the last 1..PF+1 tiles run after.
+    int t = 0, buf = 0;
+    if constexpr (PF == 1) {
+        // tile t+1 in r1 (even t) / r0 (odd t)
+        for (; t + 3 <= nt; t += 2) {
+            STEP(true, true, 0, r1, r0, t + 2);
+            __syncthreads();
+            STEP(true, true, 1, r0, r1, t + 3);
+            __syncthreads();
+        }
+        if (nt - t == 2) {
+            STEP(true, false, 0, r1, r0, 0);
+            __syncthreads();
+            buf = 1;
+        }
+    } else {
+        // rotation r1 -> r2 -> r0: tile t+1 lives in r1, r2, r0 for t = 0, 1, 2 (mod 3)
+        for (; t + 4 <= nt; t += 3) {
+            buf = t & 1;
+            STEP(true, true, buf, r1, r0, t + 3);
+            __syncthreads();
+            STEP(true, true, buf ^ 1, r2, r1, t + 4);
+            __syncthreads();
+            STEP(true, true, buf, r0, r2, t + 5);
+            __syncthreads();
+        }
+        buf = t & 1;
+        if (nt - t >= 2) {
+            STEP(true, false, buf, r1, r0, 0);
+            __syncthreads();
+            buf ^= 1;
+            if (nt - t == 3) {
+                STEP(true, false, buf, r2, r0, 0);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+    }
+    STEP(false, false, buf, r0, r0, 0);        // last tile: nothing left to stage or fetch
+    __syncthreads();
+#undef K0_OF
+#undef PA
+#undef PB
+#undef AS
+#undef BS
+#undef STEP
+    // fold the independent accumulator chains
+    f32x16 (&acc)[TM][TN] = accs[0];
+    if constexpr (NCH == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accs[1][i][j][r];
     }
 
     // ---- meet the k-split partial sums in LDS (smem is free after the last barrier)
@@ -329,8 +536,7 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
             constexpr int CG = BN / 4, RG = 256 / CG;          // column groups x row groups
             float *red = smem;                                 // [RG][BN]
             const int c4 = tid % CG, rg = tid / CG;
-            red[rg * BN + c4 * 4 + 0] = bsum[0]; red[rg * BN + c4 * 4 + 1] = bsum[1];
-            red[rg * BN + c4 * 4 + 2] = bsum[2]; red[rg * BN + c4 * 4 + 3] = bsum[3];
+            *reinterpret_cast<float4 *>(red + rg * BN + c4 * 4) = bsum;
             __syncthreads();
             if (tid < BN && (n0 + tid) < e.n_limit) {
                 float s = 0.f;
@@ -353,7 +559,8 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                epilogue_block<EPI>(e, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + j * 32, acc[i][j], lane);
+                epilogue_block<EPI>(e, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + j * 32, acc[i][j], lane,
+                                    wpre[i][j], dpre[i][j]);
     }
 }
 

@@ -128,6 +128,10 @@ int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats);
  * keeps ownership and must keep it alive until bp_destroy. */
 int bp_use_grad_buffer(bp_handle *h, void *device_ptr, size_t n_floats);
 int bp_grad_floats(bp_handle *h, size_t *n_floats);
+/* Host copies of the flat gradient buffer (synchronous): the exchange step done through host
+ * memory, for callers without a device-side collective (and for parity tests). */
+int bp_read_grads(bp_handle *h, float *host_dst, size_t n_floats);
+int bp_write_grads(bp_handle *h, const float *host_src, size_t n_floats);
 int bp_apply_update(bp_handle *h);
 /* Per-layer view of the flat buffer: offset/count (floats) of layer l's [W|b] segment. */
 int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *count);

@@ -1,0 +1,119 @@
+// tools/gemm_probe.hip -- development probe (not part of the product): times template variants
+// of bp_gemm on the C2 shapes in one process so a single GPU call compares them (interleaved
+// rounds, median).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o gpurun_out/gemm_probe tools/gemm_probe.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+#include "../dnn-for-speech-enhancement_amd/csrc/bp_kernels.h"
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak(float *out, int iters)
+{
+    f32x16 acc[NACC];
+    for (int c = 0; c < NACC; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+    float s = 0.f;
+    for (int c = 0; c < NACC; ++c) for (int r = 0; r < 16; ++r) s += acc[c][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+struct Variant { std::string name; std::function<void(hipStream_t)> run; double flops; };
+
+static float *dalloc(size_t n, float scale, unsigned seed)
+{
+    std::vector<float> h(n);
+    srand(seed);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    float *d; CK(hipMalloc(&d, n * 4 + 65536)); CK(hipMemset(d, 0, n * 4 + 65536)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF>
+static void go(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N, int dyn)
+{
+    g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>), dim3(g.tiles_m * g.tiles_n), dim3(256), dyn, st, g, e);
+}
+
+int main(int argc, char **argv)
+{
+    const int B = 256, H = 2048;
+    int LD = 2048;
+    const char *filter = argc > 1 ? argv[1] : "";
+    hipStream_t st; CK(hipStreamCreate(&st));
+    const size_t LDMAX = 2304;
+    float *Y = dalloc((size_t)B * LDMAX, 1.f, 1), *W = dalloc((size_t)H * LDMAX, 0.03f, 2), *D = dalloc((size_t)H * LDMAX, 0.f, 3);
+    float *Yo = dalloc((size_t)B * LDMAX, 0.f, 4), *dX = dalloc((size_t)B * LDMAX, 0.01f, 5), *bias = dalloc(LDMAX, 0.1f, 6);
+    float *bd = dalloc(H, 0.f, 7);
+    std::vector<Variant> vs;
+    auto fwd_args = [&](GemmArgs &g, EpiArgs &e) {
+        memset(&g, 0, sizeof(g)); memset(&e, 0, sizeof(e));
+        g.A = Y; g.lda = LD; g.B = W; g.ldb = LD; g.K = H;
+        e.C = Yo; e.ldc = LD; e.m_limit = B; e.n_limit = H; e.n_true = H; e.bias = bias; e.alpha = 1.f; e.drop_thresh = 858993459u;
+        e.seed_lo = 1; e.step = 3; e.layer = 2;
+    };
+    auto dg_args = [&](GemmArgs &g, EpiArgs &e) {
+        memset(&g, 0, sizeof(g)); memset(&e, 0, sizeof(e));
+        g.A = dX; g.lda = LD; g.B = W; g.ldb = LD; g.K = H;
+        e.C = Yo; e.ldc = LD; e.m_limit = B; e.n_limit = H; e.n_true = H; e.aux = Y; e.ldaux = LD; e.alpha = 1.f;
+    };
+    auto wg_args = [&](GemmArgs &g, EpiArgs &e) {
+        memset(&g, 0, sizeof(g)); memset(&e, 0, sizeof(e));
+        g.A = Y; g.lda = LD; g.B = dX; g.ldb = LD; g.K = B;
+        e.C = W; e.ldc = LD; e.m_limit = H; e.n_limit = H; e.n_true = H; e.aux2 = D; e.ldaux2 = LD; e.alpha = 1.f;
+        e.mom = 0.5f; e.c1 = 0.0f; e.wc = 0.f; e.ndiv = 256.f; e.bias_w = bias; e.bias_d = bd;
+    };
+    const double fl = 2.0 * B * H * H;
+#define FWD(BM, BN, BK, WM, WN, PF) vs.push_back({"fwd  " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); go<BM, BN, BK, WM, WN, true, false, EPI_FWD_HIDDEN, PF>(s, g, e, B, H, 0); }, fl})
+#define DGR(BM, BN, BK, WM, WN, PF) vs.push_back({"dgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); go<BM, BN, BK, WM, WN, true, true, EPI_DGRAD, PF>(s, g, e, B, H, 0); }, fl})
+#define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " dyn" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, fl})
+    FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);
+    FWD(64, 32, 64, 2, 1, 1); FWD(64, 32, 64, 2, 1, 2);
+    FWD(32, 32, 64, 1, 1, 1); FWD(32, 32, 64, 1, 1, 2); FWD(32, 32, 128, 1, 1, 1);
+    FWD(64, 64, 32, 2, 2, 1);
+    DGR(32, 64, 64, 1, 2, 1); DGR(32, 64, 64, 1, 2, 2); DGR(64, 32, 64, 2, 1, 1); DGR(32, 32, 64, 1, 1, 1); DGR(32, 32, 64, 1, 1, 2);
+    WGR(64, 64, 32, 2, 2, 1, 0); WGR(64, 64, 32, 2, 2, 2, 0); WGR(64, 64, 32, 2, 2, 1, 48000);
+    WGR(64, 64, 64, 2, 2, 1, 0); WGR(128, 64, 32, 2, 2, 1, 0); WGR(128, 64, 16, 2, 2, 1, 0); WGR(128, 64, 16, 2, 2, 2, 0); WGR(64, 128, 16, 2, 2, 1, 0);
+    WGR(128, 128, 16, 2, 2, 1, 0); WGR(64, 64, 16, 2, 2, 2, 0);
+    // calibration: what the matrix pipe delivers on this box (one wave per SIMD, 256 workgroups)
+    vs.push_back({"mfma peak: 1 dependent chain/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<1>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0});
+    vs.push_back({"mfma peak: 4 chains/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<4>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0 * 4});
+
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    const int lds[] = {2048};
+    for (int li = 0; li < 1; ++li) {
+    LD = lds[li];
+    printf("==== leading dimension %d floats\n", LD);
+    const int rounds = 5, iters = 20;
+    std::vector<std::vector<float>> t(vs.size());
+    for (int r = 0; r < rounds; ++r)
+        for (size_t v = 0; v < vs.size(); ++v) {
+            if (filter[0] && vs[v].name.find(filter) == std::string::npos) continue;
+            vs[v].run(st); vs[v].run(st);
+            CK(hipEventRecord(a, st));
+            for (int i = 0; i < iters; ++i) vs[v].run(st);
+            CK(hipEventRecord(b, st)); CK(hipEventSynchronize(b));
+            CK(hipGetLastError());
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            t[v].push_back(ms / iters * 1000.f);
+        }
+    for (size_t v = 0; v < vs.size(); ++v) {
+        if (t[v].empty()) continue;
+        std::sort(t[v].begin(), t[v].end());
+        const float med = t[v][t[v].size() / 2];
+        printf("%-34s med %7.2f us  min %7.2f us  %6.1f TF (%.0f%% of 157.3)\n", vs[v].name.c_str(), med, t[v][0],
+               vs[v].flops / med * 1e-6, vs[v].flops / med * 1e-6 / 157.3 * 100);
+    }
+    }
+    return 0;
+}
