@@ -36,6 +36,9 @@ struct bp_handle {
     int B, Bg;                   // local / global bunch
     int cap, chunk_frames;
     hipStream_t own_stream, stream;
+    hipStream_t side;            // wgrad+update kernels run here, overlapping the next dgrad on `stream`
+    hipEvent_t ev_d[BP_MAXLAYER], ev_w[BP_MAXLAYER]; bool w_pending[BP_MAXLAYER];
+    bool overlap;                // two-stream overlap enabled (single-device fused step)
     float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
     float *in, *in_drop, *targ, *out_dev;
@@ -85,6 +88,11 @@ extern "C" int bp_destroy(bp_handle *h)
     if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (int l = 0; l < BP_MAXLAYER; ++l) {
+        if (h->ev_d[l]) (void)hipEventDestroy(h->ev_d[l]);
+        if (h->ev_w[l]) (void)hipEventDestroy(h->ev_w[l]);
+    }
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return BP_OK;
@@ -123,7 +131,11 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
         return fail(BP_ERR_ARG, "bp_create: dropout needs bunchsize and rank_frame_offset to be multiples of 4");
     }
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
-    h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr; h->side = nullptr;
+    for (int l = 0; l < BP_MAXLAYER; ++l) { h->ev_d[l] = h->ev_w[l] = nullptr; h->w_pending[l] = false; }
+    // measured slower than the single-stream sequence on MI355X (cross-stream event hand-offs cost
+    // more than the overlap returns at ~25 us per kernel): opt-in only.
+    h->overlap = getenv("BP_OVERLAP") != nullptr;
     h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr;
     h->last_ms = 0.f; h->last_bunches = 0;
 
@@ -133,6 +145,11 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->stream = h->own_stream;
     HK(hipEventCreate(&h->ev0));
     HK(hipEventCreate(&h->ev1));
+    HK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    for (int l = 1; l < h->L; ++l) {
+        HK(hipEventCreateWithFlags(&h->ev_d[l], hipEventDisableTiming));
+        HK(hipEventCreateWithFlags(&h->ev_w[l], hipEventDisableTiming));
+    }
     const int L = h->L;
     const size_t Bp = (size_t)((h->B + 63) & ~63);             // bunch rows rounded up to a whole tile
     const size_t capp = (size_t)h->cap + 64;
@@ -167,10 +184,13 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     return BP_OK;
 }
 
+static hipError_t join_side(bp_handle *h);
+
 extern "C" int bp_set_stream(bp_handle *h, void *hip_stream)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(join_side(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return BP_OK;
@@ -180,6 +200,7 @@ extern "C" int bp_sync(bp_handle *h)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(join_side(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     return BP_OK;
 }
@@ -205,8 +226,8 @@ static EpiArgs epi_zero()
 
 // forward of weight layer l on M frames.  y_prev [M][ld_{l-1}].  train: hidden outputs get the
 // hid_omit mask; output layer writes dEdX_L (and out when out != null).
-static hipError_t launch_fwd(bp_handle *h, int l, int M, const float *y_prev, const float *targ, float *out,
-                             bool train, float alpha)
+static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, const float *targ,
+                             float *out, bool train, float alpha)
 {
     const int L = h->L, prev = h->ld[l - 1], cur = h->ld[l];
     GemmArgs g; memset(&g, 0, sizeof(g));
@@ -218,18 +239,18 @@ static hipError_t launch_fwd(bp_handle *h, int l, int M, const float *y_prev, co
         e.drop_thresh = train ? h->th_hid : 0u;
         e.seed_lo = (uint32_t)h->cfg.seed; e.seed_hi = (uint32_t)(h->cfg.seed >> 32);
         e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
-        if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_HIDDEN>(h->stream, g, e, M, cur);
-        return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>(h->stream, g, e, M, cur);
+        if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
+        return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
     }
     e.C = train ? h->dx[l] : nullptr; e.ldc = cur;
     e.aux = targ; e.ldaux = cur; e.aux2 = out; e.ldaux2 = cur;
     e.scale = 2.0f / (float)h->Bg;                       // kernSubClean: 2.0f/rows (global rows under DP)
-    if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_OUT>(h->stream, g, e, M, cur);
-    return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_OUT>(h->stream, g, e, M, cur);
+    if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_OUT>(st, g, e, M, cur);
+    return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_OUT>(st, g, e, M, cur);
 }
 
 // dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T)     (BP_GPU.cu:611-637)
-static hipError_t launch_dgrad(bp_handle *h, int l, int M)
+static hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M)
 {
     const int prev = h->ld[l - 1], cur = h->ld[l];
     GemmArgs g; memset(&g, 0, sizeof(g));
@@ -237,13 +258,13 @@ static hipError_t launch_dgrad(bp_handle *h, int l, int M)
     EpiArgs e = epi_zero();
     e.C = h->dx[l - 1]; e.ldc = prev; e.m_limit = M; e.n_limit = prev; e.n_true = h->s[l - 1];
     e.aux = h->y[l - 1]; e.ldaux = prev; e.act = h->cfg.activation;
-    if (prev <= 512) return launch<32, 32, 64, 1, 1, true, true, EPI_DGRAD>(h->stream, g, e, M, prev);
-    return launch<32, 64, 64, 1, 2, true, true, EPI_DGRAD>(h->stream, g, e, M, prev);
+    if (prev <= 512) return launch<32, 32, 64, 1, 1, true, true, EPI_DGRAD>(st, g, e, M, prev);
+    return launch<32, 64, 64, 1, 2, true, true, EPI_DGRAD>(st, g, e, M, prev);
 }
 
 // G_l = y_{l-1}^T . dEdX_l, gb_l = colsum(dEdX_l); fused momentum update (single device) or
 // store into the flat gradient buffer (data parallel).   (BP_GPU.cu:642-652)
-static hipError_t launch_wgrad(bp_handle *h, int l, int M, const float *y_prev, bool fused)
+static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, bool fused)
 {
     const int prev = h->ld[l - 1], cur = h->ld[l];
     GemmArgs g; memset(&g, 0, sizeof(g));
@@ -256,11 +277,11 @@ static hipError_t launch_wgrad(bp_handle *h, int l, int M, const float *y_prev, 
         e.mom = m; e.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; e.wc = h->cfg.weightcost;
         e.ndiv = (float)h->Bg;
         e.bias_w = h->b[l]; e.bias_d = h->db[l];
-        return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE>(h->stream, g, e, prev, cur);
+        return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE>(st, g, e, prev, cur);
     }
     e.C = h->grad + h->g_off[l];
     e.bias_g = h->grad + h->g_off[l] + (size_t)prev * cur;
-    return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_STORE>(h->stream, g, e, prev, cur);
+    return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_STORE>(st, g, e, prev, cur);
 }
 
 static hipError_t mask_range(bp_handle *h, int first, int n)
@@ -274,30 +295,69 @@ static hipError_t mask_range(bp_handle *h, int first, int n)
     return hipGetLastError();
 }
 
+// Make `stream` wait for every wgrad+update still running on the side stream.
+static hipError_t join_side(bp_handle *h)
+{
+    for (int l = 1; l < h->L; ++l)
+        if (h->w_pending[l]) {
+            hipError_t er = hipStreamWaitEvent(h->stream, h->ev_w[l], 0);
+            if (er != hipSuccess) return er;
+            h->w_pending[l] = false;
+        }
+    return hipSuccess;
+}
+static hipError_t wait_w(bp_handle *h, int l)
+{
+    if (l >= 1 && l < h->L && h->w_pending[l]) {
+        h->w_pending[l] = false;
+        return hipStreamWaitEvent(h->stream, h->ev_w[l], 0);
+    }
+    return hipSuccess;
+}
+
 // One bunch starting at chunk frame `first`: forward + backward.  fused: momentum update inside
 // the wgrad epilogues (train_bunch_single); else gradients to the flat buffer.
+//
+// Dependencies of the fused step (BP_GPU.cu:588-671 runs it serially): wgrad+update(l) needs
+// dEdX_l and y_{l-1} and must follow dgrad(l) (which reads the pre-update W_l); dgrad(l-1) does
+// not depend on it.  So wgrad+update(l) goes to the side stream and overlaps dgrad(l-1) (and the
+// next wgrad).  The next step's fwd(l) waits for wgrad(l) (W_l) and wgrad(l+1) (which reads the
+// y_l that fwd(l) overwrites); dEdX_l is rewritten only after those waits.
 static hipError_t bunch(bp_handle *h, int first, bool fused)
 {
     const int L = h->L, B = h->B;
+    const bool ov = fused && h->overlap;
     hipError_t er;
+#define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
     const float *x0 = h->in + (size_t)first * h->ld[0];
     if (h->in_drop) {
         const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
                         (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
                         (first - h->mask_lo) % B == 0;
-        if (!ok) { er = mask_range(h, first, B); if (er != hipSuccess) return er; }
+        if (!ok) { CKE(join_side(h)); CKE(mask_range(h, first, B)); }
         x0 = h->in_drop + (size_t)first * h->ld[0];
     }
     const float *tg = h->targ + (size_t)first * h->ld[L - 1];
     for (int l = 1; l < L; ++l) {
-        er = launch_fwd(h, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f);
-        if (er != hipSuccess) return er;
+        CKE(wait_w(h, l)); CKE(wait_w(h, l + 1));
+        CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
     }
+    if (ov && L == 2) CKE(hipEventRecord(h->ev_d[1], h->stream));       // dEdX_1 comes from the output epilogue
     for (int l = L - 1; l >= 1; --l) {
-        if (l != 1) { er = launch_dgrad(h, l, B); if (er != hipSuccess) return er; }
-        er = launch_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
-        if (er != hipSuccess) return er;
+        if (l != 1) {
+            CKE(launch_dgrad(h, h->stream, l, B));
+            if (ov) CKE(hipEventRecord(h->ev_d[l], h->stream));
+        }
+        if (ov) {
+            CKE(hipStreamWaitEvent(h->side, h->ev_d[(l > 1 || L == 2) ? l : 2], 0));
+            CKE(launch_wgrad(h, h->side, l, B, l == 1 ? x0 : h->y[l - 1], true));
+            CKE(hipEventRecord(h->ev_w[l], h->side));
+            h->w_pending[l] = true;
+        } else {
+            CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], fused));
+        }
     }
+#undef CKE
     return hipSuccess;
 }
 
@@ -307,6 +367,7 @@ extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, cons
     if (!h || !in) return fail(BP_ERR_ARG, "bp_upload_chunk: null argument");
     if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_upload_chunk: n_frames exceeds chunk capacity");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(join_side(h));                    // wgrad(1) of the previous chunk may still read its input rows
     const int L = h->L;
     if (n_frames > 0) {
         HIPCHK(hipMemcpy2DAsync(h->in, (size_t)h->ld[0] * 4, in, (size_t)h->s[0] * 4, (size_t)h->s[0] * 4, n_frames,
@@ -327,6 +388,7 @@ extern "C" int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed
     if (!h) return fail(BP_ERR_ARG, "null handle");
     if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_fill_chunk_synthetic: n_frames exceeds capacity");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(join_side(h));
     const int L = h->L;
     if (n_frames > 0) {
         size_t n4 = (size_t)n_frames * (h->ld[0] / 4);
@@ -351,12 +413,14 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     if (h->Bg != h->B) return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle, use bp_grads_resident + bp_apply_update");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int nb = n_frames / h->B;          // partial last bunch ignored (BP_GPU.cu:315-318)
+    HIPCHK(join_side(h));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (nb > 0 && h->in_drop) HIPCHK(mask_range(h, first_frame, nb * h->B));
     for (int i = 0; i < nb; ++i) {
         HIPCHK(bunch(h, first_frame + i * h->B, true));
         h->step++;
     }
+    HIPCHK(join_side(h));                    // the timed region ends when the last update has landed
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_bunches = nb;
     return BP_OK;
@@ -390,6 +454,7 @@ extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
     if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(join_side(h));
     HIPCHK(bunch(h, first_frame, false));
     return BP_OK;
 }
@@ -476,7 +541,7 @@ static int forward_bunch(bp_handle *h, int first, int fb)
         float alpha = 1.0f;
         if (h->cfg.dropoutflag == 1) alpha = (l == 1) ? vis_keep : hid_keep;
         const float *yp = (l == 1) ? h->in + (size_t)first * h->ld[0] : h->y[l - 1];
-        HIPCHK(launch_fwd(h, l, fb, yp, nullptr, h->out_dev, false, alpha));
+        HIPCHK(launch_fwd(h, h->stream, l, fb, yp, nullptr, h->out_dev, false, alpha));
     }
     return BP_OK;
 }
@@ -526,6 +591,7 @@ static int get_params(bp_handle *h, float *const *w, float *const *b, bool delta
 {
     if (!h || !w || !b) return fail(BP_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(join_side(h));
     for (int l = 1; l < h->L; ++l) {
         if (!w[l] || !b[l]) return fail(BP_ERR_ARG, "weights[l]/bias[l] null");
         HIPCHK(hipMemcpy2DAsync(w[l], (size_t)h->s[l] * 4, deltas ? h->dW[l] : h->W[l], (size_t)h->ld[l] * 4,
@@ -546,6 +612,7 @@ extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
         return fail(BP_ERR_ARG, "bp_time_kernel: needs a hidden->hidden layer (numlayers >= 4)");
     if (h->chunk_frames < h->B) return fail(BP_ERR_STATE, "bp_time_kernel: no resident chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(join_side(h));
     const int L = h->L, B = h->B;
     hipEvent_t a, b;
     float *scratch_w = nullptr, *scratch_d = nullptr, *scratch_b = nullptr;
@@ -554,8 +621,8 @@ extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
         if (it == 0) HIPCHK(hipEventRecord(a, h->stream));
         hipError_t er = hipSuccess;
         switch (which) {
-        case 0: er = launch_fwd(h, 2, B, h->y[1], nullptr, nullptr, true, 1.0f); break;
-        case 1: er = launch_dgrad(h, 3 < L ? 3 : 2, B); break;
+        case 0: er = launch_fwd(h, h->stream, 2, B, h->y[1], nullptr, nullptr, true, 1.0f); break;
+        case 1: er = launch_dgrad(h, h->stream, 3 < L ? 3 : 2, B); break;
         case 2: case 5: {
             // wgrad + fused update on scratch copies of W / delta (same traffic, state untouched)
             const int l = which == 2 ? 2 : 1;
@@ -569,12 +636,12 @@ extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
             }
             float *W0 = h->W[l], *D0 = h->dW[l], *b0 = h->b[l], *db0 = h->db[l];
             h->W[l] = scratch_w; h->dW[l] = scratch_d; h->b[l] = scratch_b; h->db[l] = scratch_b + h->ld[l];
-            er = launch_wgrad(h, l, B, l == 1 ? h->in : h->y[l - 1], true);
+            er = launch_wgrad(h, h->stream, l, B, l == 1 ? h->in : h->y[l - 1], true);
             h->W[l] = W0; h->dW[l] = D0; h->b[l] = b0; h->db[l] = db0;
             break;
         }
-        case 3: er = launch_fwd(h, 1, B, h->in, nullptr, nullptr, true, 1.0f); break;
-        case 4: er = launch_fwd(h, L - 1, B, h->y[L - 2], h->targ, nullptr, true, 1.0f); break;
+        case 3: er = launch_fwd(h, h->stream, 1, B, h->in, nullptr, nullptr, true, 1.0f); break;
+        case 4: er = launch_fwd(h, h->stream, L - 1, B, h->y[L - 2], h->targ, nullptr, true, 1.0f); break;
         default: HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b));
                  return fail(BP_ERR_ARG, "bp_time_kernel: unknown kernel id");
         }

@@ -1,0 +1,637 @@
+// bp_kernels.h -- CDNA4 (gfx950) kernels of the frame-wise DNN step.
+//
+// One LDS-staged fp32 MFMA GEMM template (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered
+// fmaf chain) with the step's elementwise work fused into its epilogues, replacing the
+// reference's cuBLAS Sgemm wrappers (DevFunc.h:29-67) + 10 small kernels (DevFunc.cu).
+//
+//   fwd   X = Y_prev . W  (+bias, act, dropout of the OUTPUT)   A=[m][k]  B=[k][n]
+//   dgrad dEdX_prev = act'(y_prev) * (dEdX . W^T)               A=[m][k]  B=[n][k]
+//   wgrad G = Y_prev^T . dEdX  (+ momentum update of W, b)      A=[k][m]  B=[k][n]
+//
+// Operand tiles live in LDS k-major ([k][m] / [k][n]) so that the MFMA operand fetch
+// (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) is a conflict-free ds_read_b32 of 32
+// consecutive dwords per half-wave.  k-contiguous global operands are transposed on the way
+// in (float4 global load -> 4 x ds_write_b32, odd row stride => conflict-free); m/n-contiguous
+// operands go in with ds_write_b128.  Register-staged software pipeline: global loads of k-tiles
+// t+1..t+PF are in flight while tile t is multiplied; LDS double buffered, one barrier per k-tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(std::forward<F>(f));
+    }
+}
+
+enum { EPI_FWD_HIDDEN = 0, EPI_FWD_OUT = 1, EPI_DGRAD = 2, EPI_WGRAD_UPDATE = 3, EPI_WGRAD_STORE = 4 };
+
+// The k-loop loads carry NO predicates (a predicated load makes hipcc drain vmcnt at the top of
+// every iteration, which serialises the prefetch).  Contract with the caller instead:
+//   * every operand buffer is readable for whole tiles (rows rounded up to the tile, one extra
+//     row of slack), so tile reads never leave the allocation;
+//   * rows/columns past the true extents either hold zeros (layer-width padding; dEdX rows past
+//     the bunch, which zero the k-tail of wgrad) or only feed accumulator rows that the
+//     epilogue never stores (frames past the bunch in fwd/dgrad).
+struct GemmArgs {
+    const float *A, *B;
+    int lda, ldb;            // leading dimensions (floats)
+    int K;                   // reduction extent actually looped (rounded up to BK inside)
+    int tiles_m, tiles_n;
+};
+
+struct EpiArgs {
+    float *C; int ldc;               // Y | dEdX_L | dEdX_prev | W | G
+    int m_limit, n_limit;            // rows / cols of C that exist (padded extents)
+    int n_true;                      // unpadded column count (pad columns are forced to 0)
+    const float *bias;               // fwd
+    float alpha;                     // fwd: x = alpha*acc + bias (alpha = keep in CV, BP_GPU.cu:726-746)
+    int act;                         // 0 ReLU, 1 Sigmoid
+    const float *aux; int ldaux;     // fwd_out: targ | dgrad: y_prev
+    float *aux2; int ldaux2;         // fwd_out: out (may be null) | wgrad_update: delta_W
+    float scale;                     // fwd_out: 2/n_frames (DevFunc.cu:263)
+    // wgrad update (DevFunc.cu:313-318 + 270-277)
+    float mom, c1, wc, ndiv;         // c1 = (1-m)*lr or lr ; ndiv = (float)n
+    float *bias_w, *bias_d, *bias_g; // bias / delta_bias (update) or bias-gradient (store)
+    // dropout of the produced activation (BP_GPU.cu:546-549 applied by the producer)
+    uint32_t drop_thresh, seed_lo, seed_hi, step, layer;
+    int frame_off;                   // global frame index of row 0 of this bunch
+};
+
+// ------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3,
+                                              uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __forceinline__ float act_fwd(int act, float x)
+{
+    // DevFunc.cu:67-79 (ReLU, strict > 0) | DevFunc.cu:47-54 (.bak: 1/(1+expf(-x)))
+    return act == 0 ? (x > 0.0f ? x : 0.0f) : 1.0f / (1.0f + expf(-x));
+}
+__device__ __forceinline__ float act_bwd(int act, float y)
+{
+    // DevFunc.cu:81-97 (y>0 ? 1 : 0) | :56-64 (.bak: (1-y)*y), from the post-dropout output y
+    return act == 0 ? (y > 0.0f ? 1.0f : 0.0f) : (1.0f - y) * y;
+}
+
+// ------------------------------------------------------------------ epilogue of one 32x32 block
+// C/D layout of v_mfma_f32_32x32x2_f32: lane l, reg r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+template <int EPI>
+__device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb, const f32x16 &acc, int lane,
+                                               const f32x16 &wpre, const f32x16 &dpre)
+{
+    const int n = nb + (lane & 31);
+    const int rbase = mb + 4 * (lane >> 5);
+    if (n >= e.n_limit) return;
+    if constexpr (EPI == EPI_FWD_HIDDEN) {
+        const float bn = e.bias[n];
+        const bool live = n < e.n_true;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            const int r0 = rbase + 8 * q;
+            if (e.drop_thresh) {
+                const uint64_t gf = (uint64_t)(uint32_t)(r0 + e.frame_off);
+                const uint64_t idx = (gf >> 2) * (uint64_t)(uint32_t)e.n_true + (uint32_t)n;
+                w[0] = (uint32_t)idx; w[1] = (uint32_t)(idx >> 32); w[2] = e.layer; w[3] = e.step;
+                philox4x32_10(w[0], w[1], w[2], w[3], e.seed_lo, e.seed_hi);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = r0 + j;
+                float y = act_fwd(e.act, e.alpha * acc[q * 4 + j] + bn);
+                if (!live || w[j] < e.drop_thresh) y = 0.0f;
+                if (m < e.m_limit) e.C[(size_t)m * e.ldc + n] = y;
+            }
+        }
+    } else if constexpr (EPI == EPI_FWD_OUT) {
+        const float bn = e.bias[n];
+        const bool live = n < e.n_true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + (r & 3) + 8 * (r >> 2);
+            if (m < e.m_limit) {
+                const float o = live ? e.alpha * acc[r] + bn : 0.0f;
+                if (e.aux2) e.aux2[(size_t)m * e.ldaux2 + n] = o;
+                if (e.C) {
+                    const float t = e.aux[(size_t)m * e.ldaux + n];
+                    e.C[(size_t)m * e.ldc + n] = live ? e.scale * (o - t) : 0.0f;   // kernSubClean
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_DGRAD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + (r & 3) + 8 * (r >> 2);
+            if (m < e.m_limit) {
+                const float y = e.aux[(size_t)m * e.ldaux + n];
+                e.C[(size_t)m * e.ldc + n] = act_bwd(e.act, y) * acc[r];        // kernDsigmoid*kernVecMul
+            }
+        }
+    } else if constexpr (EPI == EPI_WGRAD_UPDATE) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + (r & 3) + 8 * (r >> 2);
+            if (m < e.m_limit) {
+                const size_t i = (size_t)m * e.ldc + n;
+                const float w = wpre[r];
+                const float d = e.mom * dpre[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);    // kernUpdatedelta
+                e.aux2[i] = d;
+                e.C[i] = d + 1.0f * w;                                                     // kernAccSum
+            }
+        }
+    } else {  // EPI_WGRAD_STORE
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + (r & 3) + 8 * (r >> 2);
+            if (m < e.m_limit) e.C[(size_t)m * e.ldc + n] = acc[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ the GEMM
+// Register image of one k-tile of both operands (global -> registers -> LDS staging).
+template <int NVA, int NVB>
+struct TileRegs { float4 a[NVA]; float4 b[NVB]; };
+
+// BM x BN x BK workgroup tile, 4 waves arranged WM x WN x KS (KS = 4/(WM*WN) splits each
+// k-tile between wave groups; partial sums meet in LDS before the epilogue).
+// A_KC: A is [m][k] in memory (k contiguous) else [k][m]; B_KC: B is [n][k] else [k][n].
+// PF = k-tiles in flight in registers beyond the one being staged into LDS (1..2).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF>
+struct GemmCfg {
+    static constexpr int KS = 4 / (WM * WN);
+    static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    static constexpr int LDA_S = A_KC ? BM + 1 : BM;
+    static constexpr int LDB_S = B_KC ? BN + 1 : BN;
+    static constexpr int A_STAGE = (BK * LDA_S + 3) & ~3, B_STAGE = (BK * LDB_S + 3) & ~3;
+    static constexpr int NVA = BM * BK / 4 / 256, NVB = BN * BK / 4 / 256;
+    static constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;     // lanes per 128-byte row segment
+    static constexpr bool BIASG = (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE);
+    static_assert(WM * WN * KS == 4 && TM >= 1 && TN >= 1, "wave layout");
+    static_assert(BK % (2 * KS) == 0 && BK % 4 == 0, "BK");
+    static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
+    static_assert(PF >= 1 && PF <= 2, "PF (k-tiles in flight beyond the one being staged)");
+    using Regs = TileRegs<NVA, NVB>;
+
+    // Addressing: uniform tile base (SGPR) + per-thread 32-bit offset that never changes, so a
+    // load is one instruction and the k-advance is scalar arithmetic.
+    struct Offs { int a[NVA]; int b[NVB]; };
+    static __device__ __forceinline__ void make_offs(Offs &o, const GemmArgs &g, int tid)
+    {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int f = tid + i * 256;
+            if constexpr (A_KC) {
+                const int l8 = f % LPS, seg = f / LPS, row = seg % BM, k4 = (seg / BM) * LPS + l8;
+                o.a[i] = row * g.lda + k4 * 4;
+            } else {
+                const int c4 = f % (BM / 4), k = f / (BM / 4);
+                o.a[i] = k * g.lda + c4 * 4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) {
+            const int f = tid + i * 256;
+            if constexpr (B_KC) {
+                const int l8 = f % LPS, seg = f / LPS, row = seg % BN, k4 = (seg / BN) * LPS + l8;
+                o.b[i] = row * g.ldb + k4 * 4;
+            } else {
+                const int c4 = f % (BN / 4), k = f / (BN / 4);
+                o.b[i] = k * g.ldb + c4 * 4;
+            }
+        }
+    }
+    // uniform base of k-tile k0 for each operand
+    static __device__ __forceinline__ const float *base_a(const GemmArgs &g, int m0, int k0)
+    {
+        return A_KC ? g.A + (size_t)m0 * g.lda + k0 : g.A + (size_t)k0 * g.lda + m0;
+    }
+    static __device__ __forceinline__ const float *base_b(const GemmArgs &g, int n0, int k0)
+    {
+        return B_KC ? g.B + (size_t)n0 * g.ldb + k0 : g.B + (size_t)k0 * g.ldb + n0;
+    }
+    static __device__ __forceinline__ void load_a(Regs &r, int i, const float *pa, const Offs &o)
+    {
+        r.a[i] = *reinterpret_cast<const float4 *>(pa + o.a[i]);
+    }
+    static __device__ __forceinline__ void load_b(Regs &r, int i, const float *pb, const Offs &o)
+    {
+        r.b[i] = *reinterpret_cast<const float4 *>(pb + o.b[i]);
+    }
+    static __device__ __forceinline__ void load(Regs &r, const float *pa, const float *pb, const Offs &o)
+    {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) load_a(r, i, pa, o);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) load_b(r, i, pb, o);
+    }
+
+    // one float4 of the A / B register image -> LDS (k-major, transposing k-contiguous operands)
+    static __device__ __forceinline__ void store_a(const Regs &r, int i, float *As, int tid)
+    {
+        const int f = tid + i * 256;
+        const float4 v = r.a[i];          // (a local copy keeps the register set out of scratch)
+        if constexpr (A_KC) {
+            const int l8 = f % LPS, seg = f / LPS, row = seg % BM, k4 = (seg / BM) * LPS + l8;
+            As[(k4 * 4 + 0) * LDA_S + row] = v.x; As[(k4 * 4 + 1) * LDA_S + row] = v.y;
+            As[(k4 * 4 + 2) * LDA_S + row] = v.z; As[(k4 * 4 + 3) * LDA_S + row] = v.w;
+        } else {
+            const int c4 = f % (BM / 4), k = f / (BM / 4);
+            *reinterpret_cast<float4 *>(As + k * LDA_S + c4 * 4) = v;
+        }
+    }
+    static __device__ __forceinline__ void store_b(const Regs &r, int i, float *Bs, int tid, float4 &bsum)
+    {
+        const int f = tid + i * 256;
+        const float4 v = r.b[i];
+        if constexpr (B_KC) {
+            const int l8 = f % LPS, seg = f / LPS, row = seg % BN, k4 = (seg / BN) * LPS + l8;
+            Bs[(k4 * 4 + 0) * LDB_S + row] = v.x; Bs[(k4 * 4 + 1) * LDB_S + row] = v.y;
+            Bs[(k4 * 4 + 2) * LDB_S + row] = v.z; Bs[(k4 * 4 + 3) * LDB_S + row] = v.w;
+        } else {
+            const int c4 = f % (BN / 4), k = f / (BN / 4);
+            *reinterpret_cast<float4 *>(Bs + k * LDB_S + c4 * 4) = v;
+            if constexpr (BIASG) {   // every thread keeps the same 4 columns across k-tiles
+                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;   // used by m-tile 0 only
+            }
+        }
+    }
+    static __device__ __forceinline__ void store(const Regs &r, float *As, float *Bs, int tid, float4 &bsum)
+    {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) store_a(r, i, As, tid);
+#pragma unroll
+        for (int i = 0; i < NVB; ++i) store_b(r, i, Bs, tid, bsum);
+    }
+
+    // One k-tile: multiply the tile resident in LDS stage (As, Bs) into acc (this wave takes
+    // k-range `ks`); between the MFMAs (a) fetch the operand fragments RD steps ahead, (b) issue
+    // the global loads of a later k-tile into register image rl, (c) move the NEXT k-tile
+    // (register image rs) into the other LDS stage.  Everything except the first RD fragment
+    // reads issues while the matrix pipe is busy.  NCH independent accumulator chains
+    // (a single dependent v_mfma_f32_32x32x2_f32 chain only reaches 90 % of the issue rate).
+    static constexpr int NCH = (TM * TN == 1) ? 2 : 1;
+    template <bool DO_STORE, bool DO_LOAD>
+    static __device__ __forceinline__ void step(const float *As, const float *Bs, f32x16 (&acc)[NCH][TM][TN], int ks,
+                                                int a_off, int b_off, int kh, const Regs &rs, float *AsN, float *BsN,
+                                                Regs &rl, const float *pa, const float *pb, const Offs &o, int tid,
+                                                float4 &bsum)
+    {
+        constexpr int NK = BK / KS / 2, NP = NVA + NVB, RD = NK < 4 ? NK : 4;
+        const float *ap = As + (ks * (BK / KS) + kh) * LDA_S + a_off;
+        const float *bp = Bs + (ks * (BK / KS) + kh) * LDB_S + b_off;
+        float av[NK][TM], bv[NK][TN];
+        // hipcc's scheduler otherwise sinks every ds_read next to its MFMA (one exposed LDS latency
+        // per pair), gathers the ds_writes in front of the barrier and the global loads + their
+        // address arithmetic in front of the first MFMA; pin the intended interleave.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < RD; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[s][i] = ap[2 * s * LDA_S + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[s][j] = bp[2 * s * LDB_S + j * 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int pl = 0, ps = 0;
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[s % NCH][i][j] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[s % NCH][i][j], 0, 0, 0);
+            if (s + RD < NK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[s + RD][i] = ap[2 * (s + RD) * LDA_S + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[s + RD][j] = bp[2 * (s + RD) * LDB_S + j * 32];
+            }
+            if constexpr (DO_LOAD) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {               // load piece q goes after MFMA step q*NK/NP
+                    if (q == pl && (q * NK) / NP == s) {
+                        if (q < NVA) load_a(rl, q, pa, o); else load_b(rl, q - NVA, pb, o);
+                        ++pl;
+                    }
+                }
+            }
+            if constexpr (DO_STORE) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {               // store piece q: same slots
+                    if (q == ps && (q * NK) / NP == s) {
+                        if (q < NVA) store_a(rs, q, AsN, tid); else store_b(rs, q - NVA, BsN, tid, bsum);
+                        ++ps;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1>
+__global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e)
+{
+    using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
+    using Regs = typename Cfg::Regs;
+    constexpr int KS = Cfg::KS, TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int A_STAGE = Cfg::A_STAGE, B_STAGE = Cfg::B_STAGE, STAGE = A_STAGE + B_STAGE;
+    constexpr bool BIASG = Cfg::BIASG;
+    constexpr int RED = (KS > 1) ? (KS - 1) * WM * WN * TM * TN * 16 * 64 : 0;
+    constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = wave / (WM * WN), wq = wave % (WM * WN), wm = wq / WN, wn = wq % WN;
+
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous range of
+    // n-tiles so the W / dEdX column panels it streams stay in its private L2.
+    int tile_m, tile_n;
+    {
+        const int b = blockIdx.x;
+        if ((g.tiles_n & 7) == 0) {
+            const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3;
+            tile_n = xcd * per + j / g.tiles_m;
+            tile_m = j % g.tiles_m;
+        } else {
+            tile_m = b % g.tiles_m;
+            tile_n = b / g.tiles_m;
+        }
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);   // bias-gradient partial sums (wgrad; used by m-tile 0)
+    const bool do_bias = BIASG && tile_m == 0;
+
+    constexpr int NCH = Cfg::NCH;
+    f32x16 accs[NCH][TM][TN];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accs[c][i][j][r] = 0.0f;
+
+    const int nt = (g.K + BK - 1) / BK;
+    const int a_off = wm * TM * 32 + (lane & 31), b_off = wn * TN * 32 + (lane & 31);
+    const int kh = lane >> 5;
+
+    // W / delta tiles of the fused update are fetched up front so the HBM latency hides under
+    // the k-loop (same lane->element map as the accumulator).
+    f32x16 wpre[TM][TN], dpre[TM][TN];
+    if constexpr (EPI == EPI_WGRAD_UPDATE) {
+        if (ks == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
+                    const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = rbase + (r & 3) + 8 * (r >> 2);
+                        const size_t idx = (size_t)m * e.ldc + n;     // in-bounds by the GemmArgs contract
+                        wpre[i][j][r] = e.C[idx];
+                        dpre[i][j][r] = e.aux2[idx];
+                    }
+                }
+        }
+    }
+
+    // ---- software pipeline: LDS holds tile t (double buffered), register sets hold tiles
+    // t+1 .. t+PF in flight.  One barrier per k-tile.  Every load in the steady-state loop is
+    // unconditional (past the end the tile index is clamped and the data ignored): a
+    // conditional load turns into a phi + copy and hipcc then waits for it right away.
+    const int last_k0 = (nt - 1) * BK;
+    typename Cfg::Offs offs;
+    Cfg::make_offs(offs, g, tid);
+#define K0_OF(t) (((t) * BK) < last_k0 ? ((t) * BK) : last_k0)
+#define PA(t) Cfg::base_a(g, m0, K0_OF(t))
+#define PB(t) Cfg::base_b(g, n0, K0_OF(t))
+#define AS(buf) (smem + (buf) * STAGE)
+#define BS(buf) (smem + (buf) * STAGE + A_STAGE)
+// multiply stage `buf`; ST: store image RS into the other stage; LD: load tile TL into image RL
+#define STEP(ST, LD, buf, RS, RL, TL)                                                                      \
+    Cfg::template step<ST, LD>(AS(buf), BS(buf), accs, ks, a_off, b_off, kh, RS, AS((buf) ^ 1), BS((buf) ^ 1),    \
+                               RL, PA(TL), PB(TL), offs, tid, bsum)
+    Regs r0, r1, r2;
+    Cfg::load(r0, PA(0), PB(0), offs);
+    Cfg::store(r0, AS(0), BS(0), tid, bsum);
+    Cfg::load(r1, PA(1), PB(1), offs);
+    if constexpr (PF >= 2) Cfg::load(r2, PA(2), PB(2), offs);
+    __syncthreads();
+    // Invariant at the top of iteration t: LDS stage t&1 holds tile t; tile t+1 (and t+2 when
+    // PF == 2) are in flight / landed in registers.  The iteration multiplies tile t and, between
+    // the MFMAs, issues the global loads of tile t+1+PF and moves tile t+1 into the other stage.
+    // The steady-state loops contain no conditionals (a conditional step makes hipcc copy the
+    // accumulators between register ranges every iteration); the last 1..PF+1 tiles run after.
+    int t = 0, buf = 0;
+    if constexpr (PF == 1) {
+        // tile t+1 in r1 (even t) / r0 (odd t)
+        for (; t + 3 <= nt; t += 2) {
+            STEP(true, true, 0, r1, r0, t + 2);
+            __syncthreads();
+            STEP(true, true, 1, r0, r1, t + 3);
+            __syncthreads();
+        }
+        if (nt - t == 2) {
+            STEP(true, false, 0, r1, r0, 0);
+            __syncthreads();
+            buf = 1;
+        }
+    } else {
+        // rotation r1 -> r2 -> r0: tile t+1 lives in r1, r2, r0 for t = 0, 1, 2 (mod 3)
+        for (; t + 4 <= nt; t += 3) {
+            buf = t & 1;
+            STEP(true, true, buf, r1, r0, t + 3);
+            __syncthreads();
+            STEP(true, true, buf ^ 1, r2, r1, t + 4);
+            __syncthreads();
+            STEP(true, true, buf, r0, r2, t + 5);
+            __syncthreads();
+        }
+        buf = t & 1;
+        if (nt - t >= 2) {
+            STEP(true, false, buf, r1, r0, 0);
+            __syncthreads();
+            buf ^= 1;
+            if (nt - t == 3) {
+                STEP(true, false, buf, r2, r0, 0);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+    }
+    STEP(false, false, buf, r0, r0, 0);        // last tile: nothing left to stage or fetch
+    __syncthreads();
+#undef K0_OF
+#undef PA
+#undef PB
+#undef AS
+#undef BS
+#undef STEP
+    // fold the independent accumulator chains
+    f32x16 (&acc)[TM][TN] = accs[0];
+    if constexpr (NCH == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += accs[1][i][j][r];
+    }
+
+    // ---- meet the k-split partial sums in LDS (smem is free after the last barrier)
+    if constexpr (KS > 1) {
+        if (ks > 0) {
+            float *red = smem + ((ks - 1) * WM * WN + wq) * (TM * TN * 16 * 64);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int s = 1; s < KS; ++s) {
+                const float *red = smem + ((s - 1) * WM * WN + wq) * (TM * TN * 16 * 64);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 64 + lane];
+            }
+        }
+        if constexpr (BIASG) __syncthreads();
+    }
+
+    // ---- bias gradient: column sums of the dEdX panel this workgroup streamed (kernAccSumrow)
+    if constexpr (BIASG && !B_KC) {
+        if (do_bias) {
+            constexpr int CG = BN / 4, RG = 256 / CG;          // column groups x row groups
+            float *red = smem;                                 // [RG][BN]
+            const int c4 = tid % CG, rg = tid / CG;
+            *reinterpret_cast<float4 *>(red + rg * BN + c4 * 4) = bsum;
+            __syncthreads();
+            if (tid < BN && (n0 + tid) < e.n_limit) {
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < RG; ++r) s += red[r * BN + tid];
+                const int n = n0 + tid;
+                if constexpr (EPI == EPI_WGRAD_UPDATE) {
+                    const float d = e.mom * e.bias_d[n] - e.c1 * (s / e.ndiv + 0.0f * e.bias_w[n]);
+                    e.bias_d[n] = d;
+                    e.bias_w[n] = d + 1.0f * e.bias_w[n];
+                } else {
+                    e.bias_g[n] = s;
+                }
+            }
+        }
+    }
+
+    if (ks == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                epilogue_block<EPI>(e, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + j * 32, acc[i][j], lane,
+                                    wpre[i][j], dpre[i][j]);
+    }
+}
+
+// ------------------------------------------------------------------ small kernels
+// Visible-layer dropout of the resident chunk (BP_GPU.cu:536-539 masks the device copy of the
+// chunk in place; here the masked frames go to a second buffer so the chunk stays reusable).
+// One thread = one unit x 4 consecutive chunk rows.
+__global__ void bp_mask_input(const float *in, float *out, int ld, int width, int first_frame, int n_frames,
+                              int bunch, int frame_off, uint32_t thresh, uint32_t seed_lo, uint32_t seed_hi,
+                              uint32_t step0)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g4 = blockIdx.y;
+    if (u >= ld) return;
+    uint32_t w[4]; uint64_t cur_blk = ~0ull; uint32_t cur_step = 0;
+    for (int j = 0; j < 4; ++j) {
+        const int rel = g4 * 4 + j;
+        if (rel >= n_frames) break;
+        const int f = first_frame + rel;
+        float v = in[(size_t)f * ld + u];
+        if (u < width) {
+            const uint32_t step = step0 + (uint32_t)(rel / bunch);
+            const uint64_t gf = (uint64_t)(uint32_t)(rel % bunch + frame_off);
+            const uint64_t blk = gf >> 2;
+            if (blk != cur_blk || step != cur_step) {
+                const uint64_t idx = blk * (uint64_t)(uint32_t)width + (uint32_t)u;
+                w[0] = (uint32_t)idx; w[1] = (uint32_t)(idx >> 32); w[2] = 0u; w[3] = step;
+                philox4x32_10(w[0], w[1], w[2], w[3], seed_lo, seed_hi);
+                cur_blk = blk; cur_step = step;
+            }
+            if (w[gf & 3] < thresh) v = 0.0f;
+        }
+        out[(size_t)f * ld + u] = v;
+    }
+}
+
+// Synthetic N(0,1) fill of a padded [rows][ld] buffer (cols >= width stay 0): Philox + Box-Muller.
+__global__ void bp_fill_normal(float *buf, int ld, int width, int rows, uint32_t seed_lo, uint32_t seed_hi,
+                               uint32_t stream)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread = 4 elements
+    const size_t per_row = (size_t)(ld / 4);
+    if (i >= per_row * (size_t)rows) return;
+    const size_t r = i / per_row; const int c = (int)(i % per_row) * 4;
+    uint32_t w0 = (uint32_t)i, w1 = (uint32_t)(i >> 32), w2 = stream, w3 = 0x5EEDu;
+    philox4x32_10(w0, w1, w2, w3, seed_lo, seed_hi);
+    const float u0 = (w0 + 1.0f) * 2.3283064365386963e-10f, u1 = w1 * 2.3283064365386963e-10f;
+    const float u2 = (w2 + 1.0f) * 2.3283064365386963e-10f, u3 = w3 * 2.3283064365386963e-10f;
+    const float r0 = sqrtf(-2.0f * logf(fminf(u0, 1.0f))), r1 = sqrtf(-2.0f * logf(fminf(u2, 1.0f)));
+    float v[4] = { r0 * cosf(6.283185307179586f * u1), r0 * sinf(6.283185307179586f * u1),
+                   r1 * cosf(6.283185307179586f * u3), r1 * sinf(6.283185307179586f * u3) };
+    float4 o;
+    o.x = (c + 0 < width) ? v[0] : 0.f; o.y = (c + 1 < width) ? v[1] : 0.f;
+    o.z = (c + 2 < width) ? v[2] : 0.f; o.w = (c + 3 < width) ? v[3] : 0.f;
+    *reinterpret_cast<float4 *>(buf + r * ld + c) = o;
+}
+
+// Momentum update on a flat [W|b] gradient segment after the data-parallel sum
+// (kernUpdatedelta + kernAccSum, DevFunc.cu:313-318, 270-277); wc applies to the W part only.
+__global__ void bp_update_flat(float *w, float *d, const float *g, size_t n_w, float *bw, float *bd,
+                               const float *bg, int n_b, float mom, float c1, float wc, float ndiv)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_w; i += stride) {
+        const float wi = w[i];
+        const float di = mom * d[i] - c1 * (g[i] / ndiv + wc * wi);
+        d[i] = di; w[i] = di + 1.0f * wi;
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n_b; i += stride) {
+        const float wi = bw[i];
+        const float di = mom * bd[i] - c1 * (bg[i] / ndiv + 0.0f * wi);
+        bd[i] = di; bw[i] = di + 1.0f * wi;
+    }
+}
