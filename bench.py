@@ -73,9 +73,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    force_dp = os.environ.get("BENCH_FORCE_DP") == "1"      # exercise the data-parallel path at world size 1
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -93,7 +96,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if world == 1:
+    if world == 1 and not force_dp:
         g = dnnse_amd.BP_GPU(1, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, **kw)
         g.fill_chunk_synthetic(chunk, 20260927)
         g.sync()
@@ -162,7 +165,7 @@ def main():
                            "achieved": ach, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TF,
                            "traffic": None, "kernel_ms": ms,
                            "step_frac_of_mfma_peak": flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not force_dp and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, b)
         print(json.dumps(res), flush=True)
     if dist is not None:

@@ -32,7 +32,8 @@ __device__ __forceinline__ void static_for(F &&f)
     }
 }
 
-enum { EPI_FWD_HIDDEN = 0, EPI_FWD_OUT = 1, EPI_DGRAD = 2, EPI_WGRAD_UPDATE = 3, EPI_WGRAD_STORE = 4 };
+enum { EPI_FWD_HIDDEN = 0, EPI_FWD_OUT = 1, EPI_DGRAD = 2, EPI_WGRAD_UPDATE = 3, EPI_WGRAD_STORE = 4,
+       EPI_PARTIAL = 5 /* raw k-slice partial sums into slab blockIdx.y (split-K) */ };
 
 // The k-loop loads carry NO predicates (a predicated load makes hipcc drain vmcnt at the top of
 // every iteration, which serialises the prefetch).  Contract with the caller instead:
@@ -46,6 +47,8 @@ struct GemmArgs {
     int lda, ldb;            // leading dimensions (floats)
     int K;                   // reduction extent actually looped (rounded up to BK inside)
     int tiles_m, tiles_n;
+    int k_split;             // split-K: workgroup row blockIdx.y handles k in [y*k_split, y*k_split + K)
+    size_t slab_stride;      // split-K: floats between the partial-sum slabs of consecutive k-slices
 };
 
 struct EpiArgs {
@@ -157,7 +160,7 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
                 e.C[i] = d + 1.0f * w;                                                     // kernAccSum
             }
         }
-    } else {  // EPI_WGRAD_STORE
+    } else {  // EPI_WGRAD_STORE / EPI_PARTIAL: plain store
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = rbase + (r & 3) + 8 * (r >> 2);
@@ -350,7 +353,7 @@ struct GemmCfg {
 };
 
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1>
-__global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e)
+__global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g_in, const EpiArgs e_in)
 {
     using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
     using Regs = typename Cfg::Regs;
@@ -363,12 +366,22 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = wave / (WM * WN), wq = wave % (WM * WN), wm = wq / WN, wn = wq % WN;
+    GemmArgs g = g_in;
+    EpiArgs e = e_in;
+    if constexpr (EPI == EPI_PARTIAL) {      // this workgroup row's k-slice and output slab
+        const size_t kz = (size_t)blockIdx.y * g.k_split;
+        g.A += A_KC ? kz : kz * g.lda;
+        g.B += B_KC ? kz : kz * g.ldb;
+        e.C += (size_t)blockIdx.y * g.slab_stride;
+    }
 
     // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous range of
     // n-tiles so the W / dEdX column panels it streams stay in its private L2.
+    // Persistent over tiles (grid may be smaller than the tile count): the epilogue's stores of
+    // one tile are still draining while the next tile's k-loop runs.
+    for (int b = blockIdx.x; b < g.tiles_m * g.tiles_n; b += gridDim.x) {
     int tile_m, tile_n;
     {
-        const int b = blockIdx.x;
         if ((g.tiles_n & 7) == 0) {
             const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3;
             tile_n = xcd * per + j / g.tiles_m;
@@ -412,7 +425,8 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = rbase + (r & 3) + 8 * (r >> 2);
-                        const size_t idx = (size_t)m * e.ldc + n;     // in-bounds by the GemmArgs contract
+                        const int mc = m < e.m_limit ? m : e.m_limit - 1;   // (rows past the matrix are never stored)
+                        const size_t idx = (size_t)mc * e.ldc + n;
                         wpre[i][j][r] = e.C[idx];
                         dpre[i][j][r] = e.aux2[idx];
                     }
@@ -562,6 +576,8 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
                 epilogue_block<EPI>(e, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + j * 32, acc[i][j], lane,
                                     wpre[i][j], dpre[i][j]);
     }
+    if (b + (int)gridDim.x < g.tiles_m * g.tiles_n) __syncthreads();   // smem is reused by the next tile
+    }   // tile loop
 }
 
 // ------------------------------------------------------------------ small kernels
@@ -616,6 +632,36 @@ __global__ void bp_fill_normal(float *buf, int ld, int width, int rows, uint32_t
     o.x = (c + 0 < width) ? v[0] : 0.f; o.y = (c + 1 < width) ? v[1] : 0.f;
     o.z = (c + 2 < width) ? v[2] : 0.f; o.w = (c + 3 < width) ? v[3] : 0.f;
     *reinterpret_cast<float4 *>(buf + r * ld + c) = o;
+}
+
+// Second half of a split-K output layer: out = sum_z slab[z] + bias; dEdX = scale*(out - targ)
+// (kernSubClean, DevFunc.cu:253-268).  One thread = 4 consecutive columns of one frame.
+__global__ void bp_out_reduce(const float *slabs, size_t slab_stride, int nsplit, int M, int ld, int n_true,
+                              const float *bias, float alpha, const float *targ, float scale, float *out, float *dedx)
+{
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x, per_row = ld / 4;
+    if (c4 >= M * per_row) return;
+    const int m = c4 / per_row, n = (c4 % per_row) * 4;
+    const size_t i = (size_t)m * ld + n;
+    float4 s = *reinterpret_cast<const float4 *>(slabs + i);
+    for (int z = 1; z < nsplit; ++z) {
+        const float4 p = *reinterpret_cast<const float4 *>(slabs + z * slab_stride + i);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    const float4 b = *reinterpret_cast<const float4 *>(bias + n);
+    float o[4] = {alpha * s.x + b.x, alpha * s.y + b.y, alpha * s.z + b.z, alpha * s.w + b.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n + j >= n_true) o[j] = 0.0f;
+    if (out) *reinterpret_cast<float4 *>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dedx) {
+        const float4 t = *reinterpret_cast<const float4 *>(targ + i);
+        float4 d = make_float4(scale * (o[0] - t.x), scale * (o[1] - t.y), scale * (o[2] - t.z), scale * (o[3] - t.w));
+        if (n + 0 >= n_true) d.x = 0.f;
+        if (n + 1 >= n_true) d.y = 0.f;
+        if (n + 2 >= n_true) d.z = 0.f;
+        if (n + 3 >= n_true) d.w = 0.f;
+        *reinterpret_cast<float4 *>(dedx + i) = d;
+    }
 }
 
 // Momentum update on a flat [W|b] gradient segment after the data-parallel sum

@@ -1,0 +1,103 @@
+/*
+ * BP_GPU.h -- drop-in replacement for the reference's BP_GPU.h (class BP_GPU, BP_GPU.h:40-88)
+ * on top of the MI355X C ABI (bp_c_api.h / libbp_hip.so).  Header-only; no CUDA, HIP, cuBLAS or
+ * cuRAND types leak into the caller, so BPtrain.cc / Interface.cc-style code compiles against it
+ * with a plain C++ compiler and links with -lbp_hip.
+ *
+ * Kept verbatim from the reference (BP_GPU.h:13-14, 43-70): the macros MAXLAYER and
+ * MAXCACHEFRAME, the constructor signature, train / CrossValid / returnWeights, and the public
+ * data members.  Error convention of the reference is reproduced: a message on stdout and
+ * exit(0) (BP_GPU.cu:20-24, 929-933).
+ *
+ * Differences a caller can observe (all documented in DESIGN.md):
+ *   - `a_GPU_selected` > 1 does not fan out inside one process (the reference's multi-GPU path
+ *     is commented out and trains nothing, BP_GPU.cu:301-313); data parallelism is one process
+ *     per GPU through bp_config.global_bunchsize / rank_frame_offset.
+ *   - train_bunch_single / train_bunch_multi / cv_bunch_single take DEVICE pointers in the
+ *     reference and are only called from inside the class; they are not re-exported.
+ *   - optional behaviour switches the reference has only as source edits can be set through
+ *     environment variables before construction: BP_ACTIVATION=sigmoid|relu,
+ *     BP_MOMENTUM_RULE=classic|live, BP_SEED=<u64>, BP_DEVICE=<ordinal>.
+ */
+#ifndef BP_GPU_SHIM_H
+#define BP_GPU_SHIM_H
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "bp_c_api.h"
+
+#define MAXLAYER 10           /* BP_GPU.h:13 */
+#define MAXCACHEFRAME 200000  /* BP_GPU.h:14 */
+
+class BP_GPU
+{
+public:
+    /* BP_GPU.h:43-44 / BP_GPU.cu:10-12 */
+    BP_GPU(int a_GPU_selected, int a_numlayers, int *a_layersizes, int a_bunchsize, float a_lrate, float a_momentum,
+           float a_weightcost, float **weights, float **bias, int a_dropoutflag, float a_visible_omit, float a_hid_omit)
+        : numlayers(a_numlayers), bunchsize(a_bunchsize), lrate(a_lrate), momentum(a_momentum),
+          weightcost(a_weightcost), dropoutflag(a_dropoutflag), visible_omit(a_visible_omit), hid_omit(a_hid_omit),
+          handle_(0)
+    {
+        if (a_GPU_selected < 1) {                       /* BP_GPU.cu:20-24 */
+            printf("GPU Num %d Not In Range %d-\n", a_GPU_selected, 1);
+            exit(0);
+        }
+        printf("Use GPU Device : %d\n", a_GPU_selected);
+        bp_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.gpu_used = a_GPU_selected;
+        cfg.numlayers = a_numlayers;
+        for (int i = 0; i < MAXLAYER; ++i) layersizes[i] = 0;
+        for (int i = 0; i < a_numlayers && i < MAXLAYER; ++i) cfg.layersizes[i] = layersizes[i] = a_layersizes[i];
+        cfg.bunchsize = a_bunchsize;
+        cfg.lrate = a_lrate; cfg.momentum = a_momentum; cfg.weightcost = a_weightcost;
+        cfg.dropoutflag = a_dropoutflag; cfg.visible_omit = a_visible_omit; cfg.hid_omit = a_hid_omit;
+        const char *e;
+        if ((e = getenv("BP_ACTIVATION")) != 0) cfg.activation = strcmp(e, "sigmoid") == 0 ? 1 : 0;
+        if ((e = getenv("BP_MOMENTUM_RULE")) != 0) cfg.momentum_rule = strcmp(e, "classic") == 0 ? 1 : 0;
+        if ((e = getenv("BP_SEED")) != 0) cfg.seed = strtoull(e, 0, 10);
+        if ((e = getenv("BP_DEVICE")) != 0) cfg.device = atoi(e);
+        check(bp_create(&cfg, weights, bias, &handle_));
+        printf("Created net with %d layers, bunchsize %d.\n", numlayers, bunchsize);   /* BP_GPU.cu:196 */
+    }
+    ~BP_GPU() { bp_destroy(handle_); }
+
+    /* BP_GPU.h:50 / BP_GPU.cu:241-331 */
+    void train(int n_frames, float *in, const float *targ) { check(bp_train_chunk(handle_, n_frames, in, targ)); }
+    /* BP_GPU.h:57 / BP_GPU.cu:408-479: returns the SUM of squared errors */
+    float CrossValid(int n_frames, const float *in, const float *targ)
+    {
+        float e = 0.0f;
+        check(bp_cv_chunk(handle_, n_frames, in, targ, &e));
+        return e;
+    }
+    /* BP_GPU.h:60 / BP_GPU.cu:910-923 */
+    void returnWeights(float **weights, float **bias) { check(bp_get_weights(handle_, weights, bias)); }
+
+    int numlayers;                 /* BP_GPU.h:62-70 */
+    int layersizes[MAXLAYER];
+    int bunchsize;
+    float lrate;
+    float momentum;
+    float weightcost;
+    int dropoutflag;
+    float visible_omit;
+    float hid_omit;
+
+private:
+    BP_GPU(const BP_GPU &);
+    BP_GPU &operator=(const BP_GPU &);
+    void check(int rc)
+    {
+        if (rc != 0) {             /* reference convention: message + exit(0) */
+            printf("%s\n", bp_last_error());
+            exit(0);
+        }
+    }
+    bp_handle *handle_;
+};
+
+#endif /* BP_GPU_SHIM_H */

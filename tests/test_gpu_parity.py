@@ -45,7 +45,9 @@ CASES = [
     ([1548, 256, 192, 129], 64, 2, 0, 0, 0.001, True),           # shipped 129-bin NAT width, small hidden
     ([257 * 11, 320, 257], 96, 2, 0, 0, 0.0, True),              # C2 input width, B not a multiple of 64
     ([70, 65, 130, 33], 12, 3, 1, 0, 0.01, True),                # nothing aligned
-    ([100, 2048, 2048, 40], 256, 2, 0, 0, 0.0, True),            # full-size hidden GEMMs
+    ([100, 2048, 2048, 40], 256, 2, 0, 0, 0.0, True),            # full-size hidden GEMMs, split-K output layer
+    ([300, 1024, 257], 80, 2, 1, 1, 0.0, False),                 # split-K output layer, Sigmoid, ragged bunch
+    ([2827, 2048, 257], 256, 1, 0, 0, 0.0, True),                # C2 input/output widths, 128-row wgrad tiles on 2880
 ]
 
 

@@ -42,7 +42,9 @@ template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI,
 static void go(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N, int dyn)
 {
     g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
-    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>), dim3(g.tiles_m * g.tiles_n), dim3(256), dyn, st, g, e);
+    int grid = g.tiles_m * g.tiles_n;
+    if (dyn > 0 && grid > dyn) grid = dyn;      // `dyn` = persistent grid cap
+    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>), dim3(grid), dim3(256), 0, st, g, e);
 }
 
 int main(int argc, char **argv)
@@ -76,15 +78,16 @@ int main(int argc, char **argv)
     const double fl = 2.0 * B * H * H;
 #define FWD(BM, BN, BK, WM, WN, PF) vs.push_back({"fwd  " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); go<BM, BN, BK, WM, WN, true, false, EPI_FWD_HIDDEN, PF>(s, g, e, B, H, 0); }, fl})
 #define DGR(BM, BN, BK, WM, WN, PF) vs.push_back({"dgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); go<BM, BN, BK, WM, WN, true, true, EPI_DGRAD, PF>(s, g, e, B, H, 0); }, fl})
-#define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " dyn" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, fl})
+#define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " grid" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, fl})
     FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);
     FWD(64, 32, 64, 2, 1, 1); FWD(64, 32, 64, 2, 1, 2);
     FWD(32, 32, 64, 1, 1, 1); FWD(32, 32, 64, 1, 1, 2); FWD(32, 32, 128, 1, 1, 1);
     FWD(64, 64, 32, 2, 2, 1);
     DGR(32, 64, 64, 1, 2, 1); DGR(32, 64, 64, 1, 2, 2); DGR(64, 32, 64, 2, 1, 1); DGR(32, 32, 64, 1, 1, 1); DGR(32, 32, 64, 1, 1, 2);
-    WGR(64, 64, 32, 2, 2, 1, 0); WGR(64, 64, 32, 2, 2, 2, 0); WGR(64, 64, 32, 2, 2, 1, 48000);
-    WGR(64, 64, 64, 2, 2, 1, 0); WGR(128, 64, 32, 2, 2, 1, 0); WGR(128, 64, 16, 2, 2, 1, 0); WGR(128, 64, 16, 2, 2, 2, 0); WGR(64, 128, 16, 2, 2, 1, 0);
-    WGR(128, 128, 16, 2, 2, 1, 0); WGR(64, 64, 16, 2, 2, 2, 0);
+    WGR(64, 64, 32, 2, 2, 1, 0); WGR(64, 64, 32, 2, 2, 1, 512); WGR(64, 64, 32, 2, 2, 1, 256); WGR(64, 64, 32, 2, 2, 1, 768);
+    WGR(128, 64, 16, 2, 2, 1, 0); WGR(128, 64, 16, 2, 2, 1, 256); WGR(128, 64, 32, 2, 2, 1, 256);
+    WGR(64, 128, 16, 2, 2, 1, 0); WGR(64, 128, 16, 2, 2, 1, 256);
+    WGR(128, 128, 16, 2, 2, 1, 0); WGR(128, 128, 16, 2, 2, 1, 128);
     // calibration: what the matrix pipe delivers on this box (one wave per SIMD, 256 workgroups)
     vs.push_back({"mfma peak: 1 dependent chain/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<1>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0});
     vs.push_back({"mfma peak: 4 chains/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<4>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0 * 4});
