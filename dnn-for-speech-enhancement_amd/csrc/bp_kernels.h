@@ -96,18 +96,48 @@ __device__ __forceinline__ float act_bwd(int act, float y)
 
 // ------------------------------------------------------------------ epilogue of one 32x32 block
 // C/D layout of v_mfma_f32_32x32x2_f32: lane l, reg r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
-template <int EPI>
-__device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb, const f32x16 &acc, int lane,
-                                               const f32x16 &wpre, const f32x16 &dpre)
+// Inputs the epilogue needs from memory, fetched BEFORE the k-loop so their latency hides under
+// it: bias (fwd), targ (fwd_out) / y_prev (dgrad) / W (wgrad) in p0, delta_W (wgrad) in p1.
+struct EpiPre { float bias; f32x16 p0, p1; };
+
+// Registers [R0, R0+RN) of one 32x32 accumulator block (after an in-workgroup k-split every wave
+// finishes 16/KS of the block's registers).
+template <int EPI, int R0, int RN>
+__device__ __forceinline__ void epilogue_fetch(const EpiArgs &e, int mb, int nb, int lane, EpiPre &p)
 {
+    const int n = nb + (lane & 31);
+    const int rbase = mb + 4 * (lane >> 5);
+    if constexpr (EPI == EPI_FWD_HIDDEN || EPI == EPI_FWD_OUT) p.bias = e.bias[n];
+    if constexpr (EPI == EPI_FWD_OUT || EPI == EPI_DGRAD || EPI == EPI_WGRAD_UPDATE) {
+        if (EPI == EPI_FWD_OUT && !e.C) return;
+#pragma unroll
+        for (int r = R0; r < R0 + RN; ++r) {
+            const int m = rbase + (r & 3) + 8 * (r >> 2);
+            const int mc = m < e.m_limit ? m : e.m_limit - 1;      // (rows past the matrix are never stored)
+            if constexpr (EPI == EPI_WGRAD_UPDATE) {
+                const size_t idx = (size_t)mc * e.ldc + n;
+                p.p0[r] = e.C[idx];
+                p.p1[r] = e.aux2[idx];
+            } else {
+                p.p0[r] = e.aux[(size_t)mc * e.ldaux + n];
+            }
+        }
+    }
+}
+
+template <int EPI, int R0, int RN>
+__device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb, const f32x16 &acc, int lane,
+                                               const EpiPre &p)
+{
+    static_assert(RN % 4 == 0 && R0 % 4 == 0, "register range must cover whole 4-row groups");
     const int n = nb + (lane & 31);
     const int rbase = mb + 4 * (lane >> 5);
     if (n >= e.n_limit) return;
     if constexpr (EPI == EPI_FWD_HIDDEN) {
-        const float bn = e.bias[n];
+        const float bn = p.bias;
         const bool live = n < e.n_true;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = R0 / 4; q < (R0 + RN) / 4; ++q) {
             uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             const int r0 = rbase + 8 * q;
             if (e.drop_thresh) {
@@ -125,47 +155,67 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
             }
         }
     } else if constexpr (EPI == EPI_FWD_OUT) {
-        const float bn = e.bias[n];
+        const float bn = p.bias;
         const bool live = n < e.n_true;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = R0; r < R0 + RN; ++r) {
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             if (m < e.m_limit) {
                 const float o = live ? e.alpha * acc[r] + bn : 0.0f;
                 if (e.aux2) e.aux2[(size_t)m * e.ldaux2 + n] = o;
-                if (e.C) {
-                    const float t = e.aux[(size_t)m * e.ldaux + n];
-                    e.C[(size_t)m * e.ldc + n] = live ? e.scale * (o - t) : 0.0f;   // kernSubClean
-                }
+                if (e.C) e.C[(size_t)m * e.ldc + n] = live ? e.scale * (o - p.p0[r]) : 0.0f;   // kernSubClean
             }
         }
     } else if constexpr (EPI == EPI_DGRAD) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = R0; r < R0 + RN; ++r) {
             const int m = rbase + (r & 3) + 8 * (r >> 2);
-            if (m < e.m_limit) {
-                const float y = e.aux[(size_t)m * e.ldaux + n];
-                e.C[(size_t)m * e.ldc + n] = act_bwd(e.act, y) * acc[r];        // kernDsigmoid*kernVecMul
-            }
+            if (m < e.m_limit) e.C[(size_t)m * e.ldc + n] = act_bwd(e.act, p.p0[r]) * acc[r];   // kernDsigmoid*kernVecMul
         }
     } else if constexpr (EPI == EPI_WGRAD_UPDATE) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = R0; r < R0 + RN; ++r) {
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             if (m < e.m_limit) {
                 const size_t i = (size_t)m * e.ldc + n;
-                const float w = wpre[r];
-                const float d = e.mom * dpre[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);    // kernUpdatedelta
+                const float w = p.p0[r];
+                const float d = e.mom * p.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);      // kernUpdatedelta
                 e.aux2[i] = d;
                 e.C[i] = d + 1.0f * w;                                                     // kernAccSum
             }
         }
     } else {  // EPI_WGRAD_STORE / EPI_PARTIAL: plain store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = R0; r < R0 + RN; ++r) {
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             if (m < e.m_limit) e.C[(size_t)m * e.ldc + n] = acc[r];
         }
+    }
+}
+
+// In-workgroup k-split (KS wave groups hold partial sums of the same 32x32 block): wave KSI keeps
+// registers [KSI*16/KS, (KSI+1)*16/KS), hands the others to their owners through LDS, and finishes
+// its share -- so every wave runs 1/KS of the epilogue instead of wave group 0 running all of it.
+template <int KS, int KSI>
+__device__ __forceinline__ void ksplit_give(const f32x16 &acc, float *red, int wq, int lane)
+{
+    constexpr int RN = 16 / KS;
+#pragma unroll
+    for (int o = 0; o < KS; ++o) {
+        if (o == KSI) continue;
+#pragma unroll
+        for (int rr = 0; rr < RN; ++rr) red[(((wq * KS + o) * KS + KSI) * RN + rr) * 64 + lane] = acc[o * RN + rr];
+    }
+}
+template <int KS, int KSI>
+__device__ __forceinline__ void ksplit_take(f32x16 &acc, const float *red, int wq, int lane)
+{
+    constexpr int RN = 16 / KS;
+#pragma unroll
+    for (int src = 0; src < KS; ++src) {
+        if (src == KSI) continue;
+#pragma unroll
+        for (int rr = 0; rr < RN; ++rr) acc[KSI * RN + rr] += red[(((wq * KS + KSI) * KS + src) * RN + rr) * 64 + lane];
     }
 }
 
@@ -360,7 +410,7 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g_in, const EpiArg
     constexpr int KS = Cfg::KS, TM = Cfg::TM, TN = Cfg::TN;
     constexpr int A_STAGE = Cfg::A_STAGE, B_STAGE = Cfg::B_STAGE, STAGE = A_STAGE + B_STAGE;
     constexpr bool BIASG = Cfg::BIASG;
-    constexpr int RED = (KS > 1) ? (KS - 1) * WM * WN * TM * TN * 16 * 64 : 0;
+    constexpr int RED = (KS > 1) ? KS * WM * WN * 16 * 64 : 0;     // k-split exchange area (floats)
     constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -411,26 +461,22 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g_in, const EpiArg
     const int a_off = wm * TM * 32 + (lane & 31), b_off = wn * TN * 32 + (lane & 31);
     const int kh = lane >> 5;
 
-    // W / delta tiles of the fused update are fetched up front so the HBM latency hides under
-    // the k-loop (same lane->element map as the accumulator).
-    f32x16 wpre[TM][TN], dpre[TM][TN];
-    if constexpr (EPI == EPI_WGRAD_UPDATE) {
-        if (ks == 0) {
+    // Epilogue inputs (bias / targ / y_prev / W, delta) are fetched up front so their HBM/L2 latency
+    // hides under the k-loop (same lane->element map as the accumulator).
+    EpiPre pre[TM][TN];
+    const int mb0 = m0 + wm * TM * 32, nb0 = n0 + wn * TN * 32;
+    if constexpr (KS == 1) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * TN * 32 + j * 32 + (lane & 31);
-                    const int rbase = m0 + wm * TM * 32 + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = rbase + (r & 3) + 8 * (r >> 2);
-                        const int mc = m < e.m_limit ? m : e.m_limit - 1;   // (rows past the matrix are never stored)
-                        const size_t idx = (size_t)mc * e.ldc + n;
-                        wpre[i][j][r] = e.C[idx];
-                        dpre[i][j][r] = e.aux2[idx];
-                    }
-                }
+            for (int j = 0; j < TN; ++j) epilogue_fetch<EPI, 0, 16>(e, mb0 + i * 32, nb0 + j * 32, lane, pre[i][j]);
+    } else {
+        static_assert(KS == 1 || (TM == 1 && TN == 1), "in-workgroup k-split needs one block per wave");
+        if (ks == 0) epilogue_fetch<EPI, 0, 16 / KS>(e, mb0, nb0, lane, pre[0][0]);
+        if (ks == 1) epilogue_fetch<EPI, 16 / KS, 16 / KS>(e, mb0, nb0, lane, pre[0][0]);
+        if constexpr (KS == 4) {
+            if (ks == 2) epilogue_fetch<EPI, 8, 4>(e, mb0, nb0, lane, pre[0][0]);
+            if (ks == 3) epilogue_fetch<EPI, 12, 4>(e, mb0, nb0, lane, pre[0][0]);
         }
     }
 
@@ -517,29 +563,21 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g_in, const EpiArg
                 for (int r = 0; r < 16; ++r) acc[i][j][r] += accs[1][i][j][r];
     }
 
-    // ---- meet the k-split partial sums in LDS (smem is free after the last barrier)
+    // ---- in-workgroup k-split: exchange partial sums through LDS (smem is free after the last
+    // barrier); afterwards wave group ks owns registers [ks*16/KS, (ks+1)*16/KS) of its block
     if constexpr (KS > 1) {
-        if (ks > 0) {
-            float *red = smem + ((ks - 1) * WM * WN + wq) * (TM * TN * 16 * 64);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) red[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        if (ks == 0) ksplit_give<KS, 0>(acc[0][0], smem, wq, lane);
+        if (ks == 1) ksplit_give<KS, 1>(acc[0][0], smem, wq, lane);
+        if constexpr (KS == 4) {
+            if (ks == 2) ksplit_give<KS, 2>(acc[0][0], smem, wq, lane);
+            if (ks == 3) ksplit_give<KS, 3>(acc[0][0], smem, wq, lane);
         }
         __syncthreads();
-        if (ks == 0) {
-#pragma unroll
-            for (int s = 1; s < KS; ++s) {
-                const float *red = smem + ((s - 1) * WM * WN + wq) * (TM * TN * 16 * 64);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TN + j) * 16 + r) * 64 + lane];
-            }
+        if (ks == 0) ksplit_take<KS, 0>(acc[0][0], smem, wq, lane);
+        if (ks == 1) ksplit_take<KS, 1>(acc[0][0], smem, wq, lane);
+        if constexpr (KS == 4) {
+            if (ks == 2) ksplit_take<KS, 2>(acc[0][0], smem, wq, lane);
+            if (ks == 3) ksplit_take<KS, 3>(acc[0][0], smem, wq, lane);
         }
         if constexpr (BIASG) __syncthreads();
     }
@@ -568,13 +606,19 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g_in, const EpiArg
         }
     }
 
-    if (ks == 0) {
+    if constexpr (KS == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                epilogue_block<EPI>(e, m0 + wm * TM * 32 + i * 32, n0 + wn * TN * 32 + j * 32, acc[i][j], lane,
-                                    wpre[i][j], dpre[i][j]);
+                epilogue_block<EPI, 0, 16>(e, mb0 + i * 32, nb0 + j * 32, acc[i][j], lane, pre[i][j]);
+    } else {
+        if (ks == 0) epilogue_block<EPI, 0, 16 / KS>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+        if (ks == 1) epilogue_block<EPI, 16 / KS, 16 / KS>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+        if constexpr (KS == 4) {
+            if (ks == 2) epilogue_block<EPI, 8, 4>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+            if (ks == 3) epilogue_block<EPI, 12, 4>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+        }
     }
     if (b + (int)gridDim.x < g.tiles_m * g.tiles_n) __syncthreads();   // smem is reused by the next tile
     }   // tile loop
