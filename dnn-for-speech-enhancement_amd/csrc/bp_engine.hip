@@ -36,9 +36,7 @@ struct bp_handle {
     int B, Bg;                   // local / global bunch
     int cap, chunk_frames;
     hipStream_t own_stream, stream;
-    hipStream_t side;            // wgrad+update kernels run here, overlapping the next dgrad on `stream`
-    hipEvent_t ev_d[BP_MAXLAYER], ev_w[BP_MAXLAYER]; bool w_pending[BP_MAXLAYER];
-    bool overlap;                // two-stream overlap enabled (single-device fused step)
+    bool dual;                   // paired backward launches (bp_gemm_dual)
     float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
     float *in, *in_drop, *targ, *out_dev;
@@ -89,11 +87,6 @@ extern "C" int bp_destroy(bp_handle *h)
     if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    for (int l = 0; l < BP_MAXLAYER; ++l) {
-        if (h->ev_d[l]) (void)hipEventDestroy(h->ev_d[l]);
-        if (h->ev_w[l]) (void)hipEventDestroy(h->ev_w[l]);
-    }
-    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return BP_OK;
@@ -132,11 +125,8 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
         return fail(BP_ERR_ARG, "bp_create: dropout needs bunchsize and rank_frame_offset to be multiples of 4");
     }
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
-    h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr; h->side = nullptr;
-    for (int l = 0; l < BP_MAXLAYER; ++l) { h->ev_d[l] = h->ev_w[l] = nullptr; h->w_pending[l] = false; }
-    // measured slower than the single-stream sequence on MI355X (cross-stream event hand-offs cost
-    // more than the overlap returns at ~25 us per kernel): opt-in only.
-    h->overlap = getenv("BP_OVERLAP") != nullptr;
+    h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->dual = getenv("BP_DUAL") != nullptr;     // measured 1.5 % slower than back-to-back launches: opt-in
     h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
     h->last_ms = 0.f; h->last_bunches = 0;
 
@@ -146,11 +136,6 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->stream = h->own_stream;
     HK(hipEventCreate(&h->ev0));
     HK(hipEventCreate(&h->ev1));
-    HK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    for (int l = 1; l < h->L; ++l) {
-        HK(hipEventCreateWithFlags(&h->ev_d[l], hipEventDisableTiming));
-        HK(hipEventCreateWithFlags(&h->ev_w[l], hipEventDisableTiming));
-    }
     const int L = h->L;
     const size_t Bp = (size_t)((h->B + 63) & ~63);             // bunch rows rounded up to a whole tile
     const size_t capp = (size_t)h->cap + 64;
@@ -192,13 +177,10 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     return BP_OK;
 }
 
-static hipError_t join_side(bp_handle *h);
-
 extern "C" int bp_set_stream(bp_handle *h, void *hip_stream)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(join_side(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return BP_OK;
@@ -208,7 +190,6 @@ extern "C" int bp_sync(bp_handle *h)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(join_side(h));
     HIPCHK(hipStreamSynchronize(h->stream));
     return BP_OK;
 }
@@ -272,43 +253,110 @@ static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const f
     return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_OUT>(st, g, e, M, cur);
 }
 
+// A prepared backward GEMM: arguments + which tile configuration it uses.
+enum { CFG_DGRAD_WIDE, CFG_DGRAD_NARROW, CFG_WGRAD_WIDE, CFG_WGRAD_NARROW };
+struct Prepared { GemmArgs g; EpiArgs e; int M, N, cfg; bool fused; };
+
+using KDgradWide = GemmKernel<32, 64, 64, 1, 2, true, true, EPI_DGRAD>;
+using KDgradNarrow = GemmKernel<32, 32, 64, 1, 1, true, true, EPI_DGRAD>;
+// wgrad 128x64 tiles: 25 % less operand traffic through L2 than 64x64 (measured 30.0 vs 33.8 us on
+// the 2048x2048 layer); a narrow output layer keeps 64x64 so that more workgroups exist
+template <int EPI> using KWgradWide = GemmKernel<128, 64, 16, 2, 2, false, false, EPI>;
+template <int EPI> using KWgradNarrow = GemmKernel<64, 64, 32, 2, 2, false, false, EPI>;
+
 // dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T)     (BP_GPU.cu:611-637)
-static hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M)
+static Prepared prep_dgrad(bp_handle *h, int l, int M)
 {
     const int prev = h->ld[l - 1], cur = h->ld[l];
-    GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = h->dx[l]; g.lda = cur; g.B = h->W[l]; g.ldb = cur; g.K = cur;
-    EpiArgs e = epi_zero();
-    e.C = h->dx[l - 1]; e.ldc = prev; e.m_limit = M; e.n_limit = prev; e.n_true = h->s[l - 1];
-    e.aux = h->y[l - 1]; e.ldaux = prev; e.act = h->cfg.activation;
-    if (prev <= 512) return launch<32, 32, 64, 1, 1, true, true, EPI_DGRAD>(st, g, e, M, prev);
-    return launch<32, 64, 64, 1, 2, true, true, EPI_DGRAD>(st, g, e, M, prev);
+    Prepared p; memset(&p, 0, sizeof(p));
+    p.g.A = h->dx[l]; p.g.lda = cur; p.g.B = h->W[l]; p.g.ldb = cur; p.g.K = cur;
+    p.e = epi_zero();
+    p.e.C = h->dx[l - 1]; p.e.ldc = prev; p.e.m_limit = M; p.e.n_limit = prev; p.e.n_true = h->s[l - 1];
+    p.e.aux = h->y[l - 1]; p.e.ldaux = prev; p.e.act = h->cfg.activation;
+    p.M = M; p.N = prev; p.cfg = prev <= 512 ? CFG_DGRAD_NARROW : CFG_DGRAD_WIDE;
+    return p;
 }
 
 // G_l = y_{l-1}^T . dEdX_l, gb_l = colsum(dEdX_l); fused momentum update (single device) or
 // store into the flat gradient buffer (data parallel).   (BP_GPU.cu:642-652)
-static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, bool fused)
+static Prepared prep_wgrad(bp_handle *h, int l, int M, const float *y_prev, bool fused)
 {
     const int prev = h->ld[l - 1], cur = h->ld[l];
-    GemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = y_prev; g.lda = prev; g.B = h->dx[l]; g.ldb = cur; g.K = M;
-    EpiArgs e = epi_zero();
-    e.ldc = cur; e.m_limit = prev; e.n_limit = cur; e.n_true = h->s[l];
+    Prepared p; memset(&p, 0, sizeof(p));
+    p.g.A = y_prev; p.g.lda = prev; p.g.B = h->dx[l]; p.g.ldb = cur; p.g.K = M;
+    p.e = epi_zero();
+    p.e.ldc = cur; p.e.m_limit = prev; p.e.n_limit = cur; p.e.n_true = h->s[l];
     if (fused) {
         const float m = h->cfg.momentum, lr = h->cfg.lrate;
-        e.C = h->W[l]; e.aux2 = h->dW[l]; e.ldaux2 = cur;
-        e.mom = m; e.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; e.wc = h->cfg.weightcost;
-        e.ndiv = (float)h->Bg;
-        e.bias_w = h->b[l]; e.bias_d = h->db[l];
-        // 128x64 tiles: 25 % less operand traffic through L2 than 64x64 (measured 30.0 vs 33.8 us on
-        // the 2048x2048 layer); the narrow output layer keeps 64x64 so that more workgroups exist
-        if (cur > 512) return launch<128, 64, 16, 2, 2, false, false, EPI_WGRAD_UPDATE>(st, g, e, prev, cur);
-        return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE>(st, g, e, prev, cur);
+        p.e.C = h->W[l]; p.e.aux2 = h->dW[l]; p.e.ldaux2 = cur;
+        p.e.mom = m; p.e.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; p.e.wc = h->cfg.weightcost;
+        p.e.ndiv = (float)h->Bg;
+        p.e.bias_w = h->b[l]; p.e.bias_d = h->db[l];
+    } else {
+        p.e.C = h->grad + h->g_off[l];
+        p.e.bias_g = h->grad + h->g_off[l] + (size_t)prev * cur;
     }
-    e.C = h->grad + h->g_off[l];
-    e.bias_g = h->grad + h->g_off[l] + (size_t)prev * cur;
-    if (cur > 512) return launch<128, 64, 16, 2, 2, false, false, EPI_WGRAD_STORE>(st, g, e, prev, cur);
-    return launch<64, 64, 32, 2, 2, false, false, EPI_WGRAD_STORE>(st, g, e, prev, cur);
+    p.M = prev; p.N = cur; p.cfg = cur > 512 ? CFG_WGRAD_WIDE : CFG_WGRAD_NARROW; p.fused = fused;
+    return p;
+}
+
+template <class K>
+static hipError_t run_one(hipStream_t st, Prepared &p, int bm, int bn)
+{
+    p.g.tiles_m = (p.M + bm - 1) / bm; p.g.tiles_n = (p.N + bn - 1) / bn;
+    hipLaunchKernelGGL((bp_gemm_dual<K, K>), dim3(p.g.tiles_m * p.g.tiles_n), dim3(256), 0, st, p.g, p.e, p.g, p.e,
+                       p.g.tiles_m * p.g.tiles_n);
+    return hipGetLastError();
+}
+static hipError_t run_single(hipStream_t st, Prepared p)
+{
+    switch (p.cfg) {
+    case CFG_DGRAD_WIDE: return run_one<KDgradWide>(st, p, 32, 64);
+    case CFG_DGRAD_NARROW: return run_one<KDgradNarrow>(st, p, 32, 32);
+    case CFG_WGRAD_WIDE: return p.fused ? run_one<KWgradWide<EPI_WGRAD_UPDATE>>(st, p, 128, 64)
+                                        : run_one<KWgradWide<EPI_WGRAD_STORE>>(st, p, 128, 64);
+    default: return p.fused ? run_one<KWgradNarrow<EPI_WGRAD_UPDATE>>(st, p, 64, 64)
+                            : run_one<KWgradNarrow<EPI_WGRAD_STORE>>(st, p, 64, 64);
+    }
+}
+
+template <class KA, class KB>
+static hipError_t run_two(hipStream_t st, Prepared &a, int am, int an, Prepared &b, int bm, int bn)
+{
+    a.g.tiles_m = (a.M + am - 1) / am; a.g.tiles_n = (a.N + an - 1) / an;
+    b.g.tiles_m = (b.M + bm - 1) / bm; b.g.tiles_n = (b.N + bn - 1) / bn;
+    const int nA = a.g.tiles_m * a.g.tiles_n, nB = b.g.tiles_m * b.g.tiles_n;
+    hipLaunchKernelGGL((bp_gemm_dual<KA, KB>), dim3(nA + nB), dim3(256), 0, st, a.g, a.e, b.g, b.e, nA);
+    return hipGetLastError();
+}
+// Two independent problems in one launch when a fused instantiation exists for the pair, else
+// back to back.  A is dispatched first (the long MFMA-heavy one), B fills in beside it.
+static hipError_t run_pair(hipStream_t st, Prepared a, Prepared b, bool allow_dual)
+{
+    if (allow_dual && b.cfg >= CFG_WGRAD_WIDE) {
+        const bool fu = b.fused;
+        if (a.cfg == CFG_DGRAD_WIDE && b.cfg == CFG_WGRAD_WIDE)
+            return fu ? run_two<KDgradWide, KWgradWide<EPI_WGRAD_UPDATE>>(st, a, 32, 64, b, 128, 64)
+                      : run_two<KDgradWide, KWgradWide<EPI_WGRAD_STORE>>(st, a, 32, 64, b, 128, 64);
+        if (a.cfg == CFG_DGRAD_WIDE && b.cfg == CFG_WGRAD_NARROW)
+            return fu ? run_two<KDgradWide, KWgradNarrow<EPI_WGRAD_UPDATE>>(st, a, 32, 64, b, 64, 64)
+                      : run_two<KDgradWide, KWgradNarrow<EPI_WGRAD_STORE>>(st, a, 32, 64, b, 64, 64);
+        if (a.cfg == CFG_WGRAD_WIDE && b.cfg == CFG_WGRAD_WIDE && a.fused == fu)
+            return fu ? run_two<KWgradWide<EPI_WGRAD_UPDATE>, KWgradWide<EPI_WGRAD_UPDATE>>(st, a, 128, 64, b, 128, 64)
+                      : run_two<KWgradWide<EPI_WGRAD_STORE>, KWgradWide<EPI_WGRAD_STORE>>(st, a, 128, 64, b, 128, 64);
+        if (a.cfg == CFG_WGRAD_NARROW && b.cfg == CFG_WGRAD_NARROW && a.fused == fu)
+            return fu ? run_two<KWgradNarrow<EPI_WGRAD_UPDATE>, KWgradNarrow<EPI_WGRAD_UPDATE>>(st, a, 64, 64, b, 64, 64)
+                      : run_two<KWgradNarrow<EPI_WGRAD_STORE>, KWgradNarrow<EPI_WGRAD_STORE>>(st, a, 64, 64, b, 64, 64);
+    }
+    hipError_t er = run_single(st, a);
+    if (er != hipSuccess) return er;
+    return run_single(st, b);
+}
+
+static hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M) { return run_single(st, prep_dgrad(h, l, M)); }
+static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, bool fused)
+{
+    return run_single(st, prep_wgrad(h, l, M, y_prev, fused));
 }
 
 static hipError_t mask_range(bp_handle *h, int first, int n)
@@ -322,38 +370,13 @@ static hipError_t mask_range(bp_handle *h, int first, int n)
     return hipGetLastError();
 }
 
-// Make `stream` wait for every wgrad+update still running on the side stream.
-static hipError_t join_side(bp_handle *h)
-{
-    for (int l = 1; l < h->L; ++l)
-        if (h->w_pending[l]) {
-            hipError_t er = hipStreamWaitEvent(h->stream, h->ev_w[l], 0);
-            if (er != hipSuccess) return er;
-            h->w_pending[l] = false;
-        }
-    return hipSuccess;
-}
-static hipError_t wait_w(bp_handle *h, int l)
-{
-    if (l >= 1 && l < h->L && h->w_pending[l]) {
-        h->w_pending[l] = false;
-        return hipStreamWaitEvent(h->stream, h->ev_w[l], 0);
-    }
-    return hipSuccess;
-}
-
 // One bunch starting at chunk frame `first`: forward + backward.  fused: momentum update inside
-// the wgrad epilogues (train_bunch_single); else gradients to the flat buffer.
-//
-// Dependencies of the fused step (BP_GPU.cu:588-671 runs it serially): wgrad+update(l) needs
-// dEdX_l and y_{l-1} and must follow dgrad(l) (which reads the pre-update W_l); dgrad(l-1) does
-// not depend on it.  So wgrad+update(l) goes to the side stream and overlaps dgrad(l-1) (and the
-// next wgrad).  The next step's fwd(l) waits for wgrad(l) (W_l) and wgrad(l+1) (which reads the
-// y_l that fwd(l) overwrites); dEdX_l is rewritten only after those waits.
+// the wgrad epilogues (train_bunch_single); else gradients to the flat buffer.  Everything is
+// enqueued on one stream in the reference's order (BP_GPU.cu:518-671); every dgrad of the step
+// sees pre-update weights because wgrad+update(l) always follows dgrad(l).
 static hipError_t bunch(bp_handle *h, int first, bool fused)
 {
     const int L = h->L, B = h->B;
-    const bool ov = fused && h->overlap;
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
     const float *x0 = h->in + (size_t)first * h->ld[0];
@@ -361,26 +384,22 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
         const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
                         (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
                         (first - h->mask_lo) % B == 0;
-        if (!ok) { CKE(join_side(h)); CKE(mask_range(h, first, B)); }
+        if (!ok) CKE(mask_range(h, first, B));
         x0 = h->in_drop + (size_t)first * h->ld[0];
     }
     const float *tg = h->targ + (size_t)first * h->ld[L - 1];
-    for (int l = 1; l < L; ++l) {
-        CKE(wait_w(h, l)); CKE(wait_w(h, l + 1));
+    for (int l = 1; l < L; ++l)
         CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
-    }
-    if (ov && L == 2) CKE(hipEventRecord(h->ev_d[1], h->stream));       // dEdX_1 comes from the output epilogue
-    for (int l = L - 1; l >= 1; --l) {
-        if (l != 1) {
-            CKE(launch_dgrad(h, h->stream, l, B));
-            if (ov) CKE(hipEventRecord(h->ev_d[l], h->stream));
-        }
-        if (ov) {
-            CKE(hipStreamWaitEvent(h->side, h->ev_d[(l > 1 || L == 2) ? l : 2], 0));
-            CKE(launch_wgrad(h, h->side, l, B, l == 1 ? x0 : h->y[l - 1], true));
-            CKE(hipEventRecord(h->ev_w[l], h->side));
-            h->w_pending[l] = true;
-        } else {
+    if (h->dual && L > 2) {
+        // optional paired launches (bp_gemm_dual): dgrad(L-1); {dgrad(l-1) || wgrad(l)} for l = L-1..3;
+        // {wgrad(2) || wgrad(1)}.  wgrad(l) never shares a launch with dgrad(l), which reads W_l.
+        CKE(launch_dgrad(h, h->stream, L - 1, B));
+        for (int l = L - 1; l >= 3; --l)
+            CKE(run_pair(h->stream, prep_dgrad(h, l - 1, B), prep_wgrad(h, l, B, h->y[l - 1], fused), true));
+        CKE(run_pair(h->stream, prep_wgrad(h, 2, B, h->y[1], fused), prep_wgrad(h, 1, B, x0, fused), true));
+    } else {
+        for (int l = L - 1; l >= 1; --l) {
+            if (l != 1) CKE(launch_dgrad(h, h->stream, l, B));
             CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], fused));
         }
     }
@@ -394,7 +413,6 @@ extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, cons
     if (!h || !in) return fail(BP_ERR_ARG, "bp_upload_chunk: null argument");
     if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_upload_chunk: n_frames exceeds chunk capacity");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(join_side(h));                    // wgrad(1) of the previous chunk may still read its input rows
     const int L = h->L;
     if (n_frames > 0) {
         HIPCHK(hipMemcpy2DAsync(h->in, (size_t)h->ld[0] * 4, in, (size_t)h->s[0] * 4, (size_t)h->s[0] * 4, n_frames,
@@ -415,7 +433,6 @@ extern "C" int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed
     if (!h) return fail(BP_ERR_ARG, "null handle");
     if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_fill_chunk_synthetic: n_frames exceeds capacity");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(join_side(h));
     const int L = h->L;
     if (n_frames > 0) {
         size_t n4 = (size_t)n_frames * (h->ld[0] / 4);
@@ -440,14 +457,12 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     if (h->Bg != h->B) return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle, use bp_grads_resident + bp_apply_update");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int nb = n_frames / h->B;          // partial last bunch ignored (BP_GPU.cu:315-318)
-    HIPCHK(join_side(h));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (nb > 0 && h->in_drop) HIPCHK(mask_range(h, first_frame, nb * h->B));
     for (int i = 0; i < nb; ++i) {
         HIPCHK(bunch(h, first_frame + i * h->B, true));
         h->step++;
     }
-    HIPCHK(join_side(h));                    // the timed region ends when the last update has landed
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_bunches = nb;
     return BP_OK;
@@ -481,7 +496,6 @@ extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
     if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(join_side(h));
     HIPCHK(bunch(h, first_frame, false));
     return BP_OK;
 }
@@ -618,7 +632,6 @@ static int get_params(bp_handle *h, float *const *w, float *const *b, bool delta
 {
     if (!h || !w || !b) return fail(BP_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(join_side(h));
     for (int l = 1; l < h->L; ++l) {
         if (!w[l] || !b[l]) return fail(BP_ERR_ARG, "weights[l]/bias[l] null");
         HIPCHK(hipMemcpy2DAsync(w[l], (size_t)h->s[l] * 4, deltas ? h->dW[l] : h->W[l], (size_t)h->ld[l] * 4,
@@ -639,7 +652,6 @@ extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
         return fail(BP_ERR_ARG, "bp_time_kernel: needs a hidden->hidden layer (numlayers >= 4)");
     if (h->chunk_frames < h->B) return fail(BP_ERR_STATE, "bp_time_kernel: no resident chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(join_side(h));
     const int L = h->L, B = h->B;
     hipEvent_t a, b;
     float *scratch_w = nullptr, *scratch_d = nullptr, *scratch_b = nullptr;
