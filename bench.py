@@ -161,9 +161,21 @@ def main():
                ("wgrad_update_l1", 5))}
         fl = 2.0 * BUNCH * 2048 * 2048
         ach = fl / (ms["fwd_hidden"] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate
+        # FETCH_SIZE / WRITE_SIZE runs of this same command, KB units, FETCH doubled per the gfx950
+        # note in MI355X_MICROARCH.md): profiles/r01_pmc_hbm_traffic.json.  null when absent.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+            for k, v in pm.items():
+                if "bp_gemm<32, 64, 64, 1, 2, true, false, 0" in k:
+                    traffic = (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6
+        except Exception:
+            traffic = None
         res["roofline"] = {"bound": "mfma", "kernel": "bp_gemm<32,64,64,...,EPI_FWD_HIDDEN> (2048x2048 hidden fwd)",
                            "achieved": ach, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TF,
-                           "traffic": None, "kernel_ms": ms,
+                           "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
+                           "algorithmic_bytes": 4.0 * (2048 * 2048 + 2 * BUNCH * 2048), "kernel_ms": ms,
                            "step_frac_of_mfma_peak": flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF}
         if world == 1 and not force_dp and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, b)
