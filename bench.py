@@ -125,12 +125,13 @@ def main():
         eng.obj.fill_chunk_synthetic(chunk, 20260927 + rank)       # each rank holds its own shard of every bunch
         nb_chunk = chunk // BUNCH
         pos = 0
+        step_fn = dp.dp_step if os.environ.get("BENCH_DP_SERIAL") == "1" else dp.dp_step_overlapped
         for _ in range(args.warmup):
-            dp.dp_step(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
+            step_fn(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            dp.dp_step(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
+            step_fn(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
         barrier()
         dt = time.perf_counter() - t0
         obj = eng.obj

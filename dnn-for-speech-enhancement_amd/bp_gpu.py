@@ -31,7 +31,8 @@ ABI_SYMBOLS = [
     "bp_last_error", "bp_abi_version", "bp_build_target", "bp_create", "bp_destroy", "bp_train_chunk",
     "bp_cv_chunk", "bp_forward", "bp_get_weights", "bp_get_deltas", "bp_upload_chunk",
     "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident", "bp_grad_buffer",
-    "bp_apply_update", "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
+    "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_apply_update_layer", "bp_advance_step",
+    "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
 ]
 
 
@@ -81,6 +82,10 @@ def load_library(path=None):
     lib.bp_grads_resident.argtypes = [hp, C.c_int]
     lib.bp_grad_buffer.argtypes = [hp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.bp_apply_update.argtypes = [hp]
+    lib.bp_dp_forward.argtypes = [hp, C.c_int]
+    lib.bp_dp_backward_layer.argtypes = [hp, C.c_int]
+    lib.bp_apply_update_layer.argtypes = [hp, C.c_int]
+    lib.bp_advance_step.argtypes = [hp]
     lib.bp_use_grad_buffer.argtypes = [hp, C.c_void_p, C.c_size_t]
     lib.bp_grad_floats.argtypes = [hp, C.POINTER(C.c_size_t)]
     lib.bp_read_grads.argtypes = [hp, fp, C.c_size_t]
@@ -220,6 +225,18 @@ class BP_GPU(object):
 
     def apply_update(self):
         self._check(self._lib.bp_apply_update(self._h))
+
+    def dp_forward(self, first_frame):
+        self._check(self._lib.bp_dp_forward(self._h, int(first_frame)))
+
+    def dp_backward_layer(self, layer):
+        self._check(self._lib.bp_dp_backward_layer(self._h, int(layer)))
+
+    def apply_update_layer(self, layer):
+        self._check(self._lib.bp_apply_update_layer(self._h, int(layer)))
+
+    def advance_step(self):
+        self._check(self._lib.bp_advance_step(self._h))
 
     def grad_buffer(self):
         p, n = C.c_void_p(), C.c_size_t()

@@ -44,6 +44,7 @@ struct bp_handle {
     float *grad; size_t grad_floats; size_t g_off[BP_MAXLAYER], g_cnt[BP_MAXLAYER];
     float *host_out;             // pinned staging for CV outputs
     uint32_t step;               // bunches trained so far (dropout stream position)
+    int dp_first, dp_next_layer; // layer-by-layer data-parallel backward in progress
     long mask_lo, mask_hi; uint32_t mask_step0;
     uint32_t th_vis, th_hid;
     hipEvent_t ev0, ev1; float last_ms; int last_bunches;
@@ -117,7 +118,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->cap = cfg->max_chunk_frames > 0 ? cfg->max_chunk_frames : BP_MAXCACHEFRAME;
     if (h->cap < h->B) h->cap = h->B;
     h->chunk_frames = 0;
-    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0;
+    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0; h->dp_first = 0; h->dp_next_layer = 0;
     h->th_vis = cfg->dropoutflag == 1 ? drop_threshold(cfg->visible_omit) : 0u;
     h->th_hid = cfg->dropoutflag == 1 ? drop_threshold(cfg->hid_omit) : 0u;
     if (cfg->dropoutflag == 1 && (h->B % 4 != 0 || cfg->rank_frame_offset % 4 != 0)) {
@@ -489,15 +490,56 @@ extern "C" int bp_train_chunk(bp_handle *h, int n_frames, const float *in, const
 }
 
 // ------------------------------------------------------------------ data-parallel split
-extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
+static hipError_t dp_input(bp_handle *h, int first, const float **x0)
+{
+    *x0 = h->in + (size_t)first * h->ld[0];
+    if (h->in_drop) {
+        const int B = h->B;
+        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
+                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
+                        (first - h->mask_lo) % B == 0;
+        if (!ok) { hipError_t er = mask_range(h, first, B); if (er != hipSuccess) return er; }
+        *x0 = h->in_drop + (size_t)first * h->ld[0];
+    }
+    return hipSuccess;
+}
+
+extern "C" int bp_dp_forward(bp_handle *h, int first_frame)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
     if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
-        return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
+        return fail(BP_ERR_ARG, "bp_dp_forward: bunch outside the resident chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(bunch(h, first_frame, false));
+    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
+    const float *x0;
+    HIPCHK(dp_input(h, first_frame, &x0));
+    const float *tg = h->targ + (size_t)first_frame * h->ld[h->L - 1];
+    for (int l = 1; l < h->L; ++l)
+        HIPCHK(launch_fwd(h, h->stream, l, h->B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
+    h->dp_first = first_frame; h->dp_next_layer = h->L - 1;
     return BP_OK;
+}
+
+extern "C" int bp_dp_backward_layer(bp_handle *h, int layer)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_backward_layer: layer out of range");
+    if (layer != h->dp_next_layer)
+        return fail(BP_ERR_STATE, "bp_dp_backward_layer: call bp_dp_forward first, then layers numlayers-1 ... 1 in order");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const float *x0;
+    HIPCHK(dp_input(h, h->dp_first, &x0));
+    if (layer != 1) HIPCHK(launch_dgrad(h, h->stream, layer, h->B));
+    HIPCHK(launch_wgrad(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], false));
+    h->dp_next_layer = layer - 1;
+    return BP_OK;
+}
+
+extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
+{
+    int r = bp_dp_forward(h, first_frame);
+    for (int l = h ? h->L - 1 : 0; r == BP_OK && l >= 1; --l) r = bp_dp_backward_layer(h, l);
+    return r;
 }
 
 extern "C" int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats)
@@ -555,22 +597,37 @@ extern "C" int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *c
     return BP_OK;
 }
 
-extern "C" int bp_apply_update(bp_handle *h)
+extern "C" int bp_apply_update_layer(bp_handle *h, int l)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (!h->grad) return fail(BP_ERR_STATE, "bp_apply_update: no gradients (call bp_grads_resident first)");
+    if (l < 1 || l >= h->L) return fail(BP_ERR_ARG, "bp_apply_update_layer: layer out of range");
+    if (!h->grad) return fail(BP_ERR_STATE, "bp_apply_update_layer: no gradients (call bp_grads_resident first)");
     HIPCHK(hipSetDevice(h->cfg.device));
     const float m = h->cfg.momentum, lr = h->cfg.lrate;
     const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
-    for (int l = h->L - 1; l >= 1; --l) {
-        const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
-        const float *g = h->grad + h->g_off[l];
-        hipLaunchKernelGGL(bp_update_flat, dim3(2048), dim3(256), 0, h->stream, h->W[l], h->dW[l], g, nw, h->b[l],
-                           h->db[l], g + nw, h->ld[l], m, c1, h->cfg.weightcost, (float)h->Bg);
-        HIPCHK(hipGetLastError());
-    }
+    const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
+    const float *g = h->grad + h->g_off[l];
+    hipLaunchKernelGGL(bp_update_flat, dim3(2048), dim3(256), 0, h->stream, h->W[l], h->dW[l], g, nw, h->b[l], h->db[l],
+                       g + nw, h->ld[l], m, c1, h->cfg.weightcost, (float)h->Bg);
+    HIPCHK(hipGetLastError());
+    return BP_OK;
+}
+
+extern "C" int bp_advance_step(bp_handle *h)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
     h->step++;
     return BP_OK;
+}
+
+extern "C" int bp_apply_update(bp_handle *h)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    for (int l = h->L - 1; l >= 1; --l) {
+        int r = bp_apply_update_layer(h, l);
+        if (r != BP_OK) return r;
+    }
+    return bp_advance_step(h);
 }
 
 // ------------------------------------------------------------------ inference / CV

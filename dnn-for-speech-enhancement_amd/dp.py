@@ -29,12 +29,29 @@ class HipEngine(object):
         self.obj.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.segments = [self.obj.grad_layout(l) for l in range(1, len(layersizes))]
 
+        self.nlayers = len(layersizes)
+
     def grads(self, first_frame):
         self.obj.grads_resident(first_frame)
         return self.grad
 
     def update(self):
         self.obj.apply_update()
+
+    # layer-by-layer interface (exchange of layer l overlaps the backward of the layers below)
+    def forward(self, first_frame):
+        self.obj.dp_forward(first_frame)
+
+    def backward_layer(self, l):
+        self.obj.dp_backward_layer(l)
+        off, cnt = self.segments[l - 1]
+        return self.grad[off:off + cnt]
+
+    def update_layer(self, l):
+        self.obj.apply_update_layer(l)
+
+    def advance(self):
+        self.obj.advance_step()
 
 
 def dp_step(engine, dist, first_frame):
@@ -43,6 +60,24 @@ def dp_step(engine, dist, first_frame):
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(g, op=dist.ReduceOp.SUM)
     engine.update()
+
+
+def dp_step_overlapped(engine, dist, first_frame):
+    """One data-parallel minibatch with the exchange pipelined against the backward pass: as soon
+    as layer l's [W|b] gradient segment is complete its all-reduce is launched (async; RCCL runs
+    it on its own stream, ordered after the producing kernels) while dgrad/wgrad of the layers
+    below continue; each layer is updated when its sum has landed.  Same arithmetic as dp_step."""
+    engine.forward(first_frame)
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    works = []
+    for l in range(engine.nlayers - 1, 0, -1):
+        seg = engine.backward_layer(l)
+        works.append((l, dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True) if multi else None))
+    for l, w in works:
+        if w is not None:
+            w.wait()
+        engine.update_layer(l)
+    engine.advance()
 
 
 def shard_rows(n_frames, global_bunch, world, rank):

@@ -122,6 +122,17 @@ int bp_sync(bp_handle *h);
  * the caller sums that buffer over ranks (RCCL all-reduce), then bp_apply_update runs
  * kernUpdatedelta + kernAccSum (DevFunc.cu:313-318, 270-277) with n = global_bunchsize. */
 int bp_grads_resident(bp_handle *h, int first_frame);            /* one local bunch          */
+/* The same, layer by layer, so that the exchange of layer l's gradient segment can overlap the
+ * backward of the layers below it: bp_dp_forward (forward + output-layer dEdX), then
+ * bp_dp_backward_layer for layer = numlayers-1 ... 1 (dgrad + wgrad of that layer; afterwards
+ * segment bp_grad_layout(layer) of the flat buffer is complete), then bp_apply_update_layer in
+ * any order once a segment has been summed, then bp_advance_step.
+ * bp_grads_resident == bp_dp_forward + every bp_dp_backward_layer;
+ * bp_apply_update   == every bp_apply_update_layer + bp_advance_step. */
+int bp_dp_forward(bp_handle *h, int first_frame);
+int bp_dp_backward_layer(bp_handle *h, int layer);
+int bp_apply_update_layer(bp_handle *h, int layer);
+int bp_advance_step(bp_handle *h);
 int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats);
 /* Adopt caller-owned device memory (e.g. a tensor the communication library already knows) as
  * the flat gradient buffer; n_floats must equal the size bp_grad_buffer reports.  The caller

@@ -35,6 +35,26 @@ class OracleEngine(object):
         self.flat.copy_(self.torch.from_numpy(np.concatenate(parts)))
         return self.flat
 
+    # layer-by-layer interface used by dp_step_overlapped
+    nlayers = len(LS)
+
+    def forward(self, first_frame):
+        self.grads(first_frame)                   # the oracle computes every layer at once
+        self._stash = self.flat.clone()
+        self.flat.zero_()
+
+    def backward_layer(self, l):
+        off = sum(a + c for a, c in self.sizes[:l - 1])
+        cnt = sum(self.sizes[l - 1])
+        self.flat[off:off + cnt] = self._stash[off:off + cnt]
+        return self.flat[off:off + cnt]
+
+    def update_layer(self, l):
+        pass                                      # applied for all layers in advance()
+
+    def advance(self):
+        self.update()
+
     def update(self):
         g = self.flat.numpy()
         gw, gb, o = [None], [None], 0
@@ -45,7 +65,7 @@ class OracleEngine(object):
         self.o.update(gw, gb, BG)
 
 
-def _worker(rank, port, q):
+def _worker(rank, port, q, overlapped):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
@@ -65,19 +85,20 @@ def _worker(rank, port, q):
     eng = OracleEngine(O, torch, W, b, x[rows], t[rows], WORLD)
     lb = BG // WORLD
     for i in range(NB):
-        dp.dp_step(eng, dist, i * lb)
+        (dp.dp_step_overlapped if overlapped else dp.dp_step)(eng, dist, i * lb)
     q.put((rank, [w.copy() for w in eng.o.W[1:]], [v.copy() for v in eng.o.b[1:]], rows[:4].tolist(), len(rows)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_device(oracle_mod):
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_two_rank_gloo_matches_single_device(oracle_mod, overlapped):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_worker, args=(r, port, q)) for r in range(WORLD)]
+    ps = [ctx.Process(target=_worker, args=(r, port, q, overlapped)) for r in range(WORLD)]
     for p in ps:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(WORLD)], key=lambda r: r[0])

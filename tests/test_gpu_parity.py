@@ -117,7 +117,22 @@ def test_dp_split_equals_fused_step(pkg, oracle_mod):
     ws, bs = s.get_weights()
     for l in range(1, len(ls)):
         assert relerr(ws[l], wa[l]) < 1e-6 and relerr(bs[l], ba[l]) < 1e-6
-    a.close(); s.close()
+    # layer-by-layer form of the same split (what the overlapped exchange drives)
+    s2 = _mk(pkg, ls, B, W, b)
+    s2.upload_chunk(x, t)
+    for i in range(2):
+        s2.dp_forward(i * B)
+        for l in range(len(ls) - 1, 0, -1):
+            s2.dp_backward_layer(l)
+        for l in range(1, len(ls)):
+            s2.apply_update_layer(l)
+        s2.advance_step()
+    w2, b2 = s2.get_weights()
+    for l in range(1, len(ls)):
+        assert np.array_equal(w2[l], ws[l]) and np.array_equal(b2[l], bs[l])
+    with pytest.raises(pkg.BPError):
+        s2.dp_backward_layer(1)                     # out of order: no forward in progress
+    a.close(); s.close(); s2.close()
     # two "ranks" on one GPU: shard gradients summed on the host == oracle on the global bunch
     Bg = 2 * B
     r0 = _mk(pkg, ls, B, W, b, global_bunchsize=Bg, rank_frame_offset=0, gpu_used=2)
