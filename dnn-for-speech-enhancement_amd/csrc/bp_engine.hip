@@ -37,6 +37,7 @@ struct bp_handle {
     int cap, chunk_frames;
     hipStream_t own_stream, stream;
     bool dual;                   // paired backward launches (bp_gemm_dual)
+    bool grouped;                // all wide wgrad+update problems of a step in one grouped launch
     float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
     float *in, *in_drop, *targ, *out_dev;
@@ -127,6 +128,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     }
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
     h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
+    h->grouped = getenv("BP_NO_GROUPED") == nullptr;
     h->dual = getenv("BP_DUAL") != nullptr;     // measured 1.5 % slower than back-to-back launches: opt-in
     h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
     h->last_ms = 0.f; h->last_bunches = 0;
@@ -354,6 +356,31 @@ static hipError_t run_pair(hipStream_t st, Prepared a, Prepared b, bool allow_du
     return run_single(st, b);
 }
 
+// Several wgrad problems in one grouped launch when they all use the wide configuration, else one
+// launch each.
+template <int EPI>
+static hipError_t run_multi_wide(hipStream_t st, Prepared *ps, int n)
+{
+    MultiArgs a; memset(&a, 0, sizeof(a));
+    int t = 0;
+    for (int i = 0; i < n; ++i) {
+        ps[i].g.tiles_m = (ps[i].M + 127) / 128; ps[i].g.tiles_n = (ps[i].N + 63) / 64;
+        a.g[i] = ps[i].g; a.e[i] = ps[i].e; a.first_tile[i] = t;
+        t += ps[i].g.tiles_m * ps[i].g.tiles_n;
+    }
+    a.first_tile[n] = t; a.n = n;
+    hipLaunchKernelGGL((bp_gemm_multi<KWgradWide<EPI>>), dim3(t), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
+{
+    bool wide = grouped && n >= 2 && n <= 4;
+    for (int i = 0; i < n; ++i) wide = wide && ps[i].cfg == CFG_WGRAD_WIDE && ps[i].fused == ps[0].fused;
+    if (wide) return ps[0].fused ? run_multi_wide<EPI_WGRAD_UPDATE>(st, ps, n) : run_multi_wide<EPI_WGRAD_STORE>(st, ps, n);
+    for (int i = 0; i < n; ++i) { hipError_t er = run_single(st, ps[i]); if (er != hipSuccess) return er; }
+    return hipSuccess;
+}
+
 static hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M) { return run_single(st, prep_dgrad(h, l, M)); }
 static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, bool fused)
 {
@@ -398,6 +425,19 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
         for (int l = L - 1; l >= 3; --l)
             CKE(run_pair(h->stream, prep_dgrad(h, l - 1, B), prep_wgrad(h, l, B, h->y[l - 1], fused), true));
         CKE(run_pair(h->stream, prep_wgrad(h, 2, B, h->y[1], fused), prep_wgrad(h, 1, B, x0, fused), true));
+    } else if (h->grouped) {
+        // Every dgrad of the step reads pre-update weights (BP_GPU.cu:636 runs before :643-652 of the
+        // same layer and the lower layers' updates come later), so the wgrad+update problems can all
+        // wait until the last dgrad and then share ONE grouped launch (bp_gemm_multi), largest first.
+        // A narrow layer (output layer) keeps its own small launch right after its dgrad.
+        Prepared ws[BP_MAXLAYER]; int nw = 0;
+        for (int l = L - 1; l >= 1; --l) {
+            if (l != 1) CKE(launch_dgrad(h, h->stream, l, B));
+            Prepared p = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
+            if (p.cfg == CFG_WGRAD_WIDE && nw < 4) ws[nw++] = p; else CKE(run_single(h->stream, p));
+        }
+        for (int i = 0; i < nw / 2; ++i) { Prepared t = ws[i]; ws[i] = ws[nw - 1 - i]; ws[nw - 1 - i] = t; }  // layer 1 first
+        if (nw) CKE(run_wgrads(h->stream, ws, nw, true));
     } else {
         for (int l = L - 1; l >= 1; --l) {
             if (l != 1) CKE(launch_dgrad(h, h->stream, l, B));

@@ -105,22 +105,34 @@ struct EpiPre { float bias; f32x16 p0, p1; };
 template <int EPI, int R0, int RN>
 __device__ __forceinline__ void epilogue_fetch(const EpiArgs &e, int mb, int nb, int lane, EpiPre &p)
 {
+    if constexpr (EPI == EPI_WGRAD_UPDATE) {
+        // transposed block (GemmCfg::SWAP): lane -> row m, registers 4q..4q+3 -> columns n0..n0+3
+        const int m = mb + (lane & 31);
+        const int mc = m < e.m_limit ? m : e.m_limit - 1;          // (rows past the matrix are never stored)
+#pragma unroll
+        for (int q = R0 / 4; q < (R0 + RN) / 4; ++q) {
+            const size_t idx = (size_t)mc * e.ldc + nb + 8 * q + 4 * (lane >> 5);
+#if defined(BP_ABLATE) && (BP_ABLATE & 16)
+            const float4 w = make_float4(0.f, 0.f, 0.f, 0.f), d = w; (void)idx;
+#else
+            const float4 w = *reinterpret_cast<const float4 *>(e.C + idx);
+            const float4 d = *reinterpret_cast<const float4 *>(e.aux2 + idx);
+#endif
+            p.p0[4 * q + 0] = w.x; p.p0[4 * q + 1] = w.y; p.p0[4 * q + 2] = w.z; p.p0[4 * q + 3] = w.w;
+            p.p1[4 * q + 0] = d.x; p.p1[4 * q + 1] = d.y; p.p1[4 * q + 2] = d.z; p.p1[4 * q + 3] = d.w;
+        }
+        return;
+    }
     const int n = nb + (lane & 31);
     const int rbase = mb + 4 * (lane >> 5);
     if constexpr (EPI == EPI_FWD_HIDDEN || EPI == EPI_FWD_OUT) p.bias = e.bias[n];
-    if constexpr (EPI == EPI_FWD_OUT || EPI == EPI_DGRAD || EPI == EPI_WGRAD_UPDATE) {
+    if constexpr (EPI == EPI_FWD_OUT || EPI == EPI_DGRAD) {
         if (EPI == EPI_FWD_OUT && !e.C) return;
 #pragma unroll
         for (int r = R0; r < R0 + RN; ++r) {
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             const int mc = m < e.m_limit ? m : e.m_limit - 1;      // (rows past the matrix are never stored)
-            if constexpr (EPI == EPI_WGRAD_UPDATE) {
-                const size_t idx = (size_t)mc * e.ldc + n;
-                p.p0[r] = e.C[idx];
-                p.p1[r] = e.aux2[idx];
-            } else {
-                p.p0[r] = e.aux[(size_t)mc * e.ldaux + n];
-            }
+            p.p0[r] = e.aux[(size_t)mc * e.ldaux + n];
         }
     }
 }
@@ -130,6 +142,35 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
                                                const EpiPre &p)
 {
     static_assert(RN % 4 == 0 && R0 % 4 == 0, "register range must cover whole 4-row groups");
+    if constexpr (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) {
+        // transposed block (GemmCfg::SWAP): lane -> row m, registers 4q..4q+3 -> columns n0..n0+3
+        const int m = mb + (lane & 31);
+        if (m >= e.m_limit) return;
+#pragma unroll
+        for (int q = R0 / 4; q < (R0 + RN) / 4; ++q) {
+            const int n0 = nb + 8 * q + 4 * (lane >> 5);
+            if (n0 >= e.n_limit) continue;
+            const size_t i = (size_t)m * e.ldc + n0;
+            if constexpr (EPI == EPI_WGRAD_UPDATE) {
+                float dv[4], wv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float w = p.p0[4 * q + j];
+                    const float d = e.mom * p.p1[4 * q + j] - e.c1 * (acc[4 * q + j] / e.ndiv + e.wc * w);   // kernUpdatedelta
+                    dv[j] = d; wv[j] = d + 1.0f * w;                                                         // kernAccSum
+                }
+#if defined(BP_ABLATE) && (BP_ABLATE & 8)
+                if (dv[0] == 1.2345e-30f) e.C[i] = dv[0];
+#else
+                *reinterpret_cast<float4 *>(e.aux2 + i) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+                *reinterpret_cast<float4 *>(e.C + i) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+#endif
+            } else {
+                *reinterpret_cast<float4 *>(e.C + i) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            }
+        }
+        return;
+    }
     const int n = nb + (lane & 31);
     const int rbase = mb + 4 * (lane >> 5);
     if (n >= e.n_limit) return;
@@ -172,19 +213,9 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             if (m < e.m_limit) e.C[(size_t)m * e.ldc + n] = act_bwd(e.act, p.p0[r]) * acc[r];   // kernDsigmoid*kernVecMul
         }
-    } else if constexpr (EPI == EPI_WGRAD_UPDATE) {
-#pragma unroll
-        for (int r = R0; r < R0 + RN; ++r) {
-            const int m = rbase + (r & 3) + 8 * (r >> 2);
-            if (m < e.m_limit) {
-                const size_t i = (size_t)m * e.ldc + n;
-                const float w = p.p0[r];
-                const float d = e.mom * p.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);      // kernUpdatedelta
-                e.aux2[i] = d;
-                e.C[i] = d + 1.0f * w;                                                     // kernAccSum
-            }
-        }
-    } else {  // EPI_WGRAD_STORE / EPI_PARTIAL: plain store
+    } else if constexpr (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) {
+        // handled above (transposed layout)
+    } else {  // EPI_PARTIAL: plain store
 #pragma unroll
         for (int r = R0; r < R0 + RN; ++r) {
             const int m = rbase + (r & 3) + 8 * (r >> 2);
@@ -238,6 +269,11 @@ struct GemmCfg {
     static constexpr int NVA = BM * BK / 4 / 256, NVB = BN * BK / 4 / 256;
     static constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;     // lanes per 128-byte row segment
     static constexpr bool BIASG = (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE);
+    // wgrad computes the TRANSPOSED 32x32 blocks (operands swapped in the MFMA): a lane then holds
+    // one row m of W/delta/G and, in registers 4q..4q+3, four CONSECUTIVE columns -- so the epilogue
+    // reads and writes W, delta, G as float4 (4x fewer memory instructions than one dword per
+    // register; the update's loads/stores are instruction-issue bound, not bandwidth bound).
+    static constexpr bool SWAP = BIASG;
     static_assert(WM * WN * KS == 4 && TM >= 1 && TN >= 1, "wave layout");
     static_assert(BK % (2 * KS) == 0 && BK % 4 == 0, "BK");
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
@@ -371,8 +407,9 @@ struct GemmCfg {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[s % NCH][i][j] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[s % NCH][i][j], 0, 0, 0);
+                    acc[s % NCH][i][j] = SWAP
+                        ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[s][j], av[s][i], acc[s % NCH][i][j], 0, 0, 0)
+                        : __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[s % NCH][i][j], 0, 0, 0);
             if (s + RD < NK) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[s + RD][i] = ap[2 * (s + RD) * LDA_S + i * 32];
@@ -637,6 +674,28 @@ __global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e
     using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     K::run(g, e, blockIdx.x, gridDim.x, blockIdx.y, smem);
+}
+
+// Up to 4 INDEPENDENT problems of the same tile configuration in one launch (grouped GEMM): the
+// wgrad+update of several layers after the last dgrad of the step.  Each problem alone is short
+// (K = bunch = 256: 16 k-tiles per workgroup) and its workgroups run in lockstep -- prologue, MFMA
+// phase and the W/delta write-back each hit the chip all at once.  In one launch of ~7 rounds of
+// workgroups the rounds drift apart, so the HBM phases of some overlap the MFMA phases of others
+// and only one launch boundary / cold start is paid.
+struct MultiArgs {
+    GemmArgs g[4];
+    EpiArgs e[4];
+    int first_tile[5];       // first_tile[p] .. first_tile[p+1]-1 = workgroups of problem p
+    int n;
+};
+template <class K>
+__global__ __launch_bounds__(256) void bp_gemm_multi(const MultiArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
+    const int b = blockIdx.x;
+    int p = 0;
+    while (p + 1 < a.n && b >= a.first_tile[p + 1]) ++p;
+    K::run(a.g[p], a.e[p], b - a.first_tile[p], a.first_tile[p + 1] - a.first_tile[p], 0, smem);
 }
 
 // Two INDEPENDENT problems in one launch: workgroups [0, nA) run problem A, the rest problem B

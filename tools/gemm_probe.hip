@@ -50,12 +50,13 @@ static void go(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N, int d
 int main(int argc, char **argv)
 {
     const int B = 256, H = 2048;
+    const int KW = argc > 3 ? atoi(argv[3]) : 256;    // reduction length (frames) of the wgrad variants
     int LD = 2048;
     const char *filter = argc > 1 ? argv[1] : "";
     hipStream_t st; CK(hipStreamCreate(&st));
     const size_t LDMAX = 2304;
-    float *Y = dalloc((size_t)B * LDMAX, 1.f, 1), *W = dalloc((size_t)H * LDMAX, 0.03f, 2), *D = dalloc((size_t)H * LDMAX, 0.f, 3);
-    float *Yo = dalloc((size_t)B * LDMAX, 0.f, 4), *dX = dalloc((size_t)B * LDMAX, 0.01f, 5), *bias = dalloc(LDMAX, 0.1f, 6);
+    float *Y = dalloc((size_t)2048 * LDMAX, 1.f, 1), *W = dalloc((size_t)H * LDMAX, 0.03f, 2), *D = dalloc((size_t)H * LDMAX, 0.f, 3);
+    float *Yo = dalloc((size_t)B * LDMAX, 0.f, 4), *dX = dalloc((size_t)2048 * LDMAX, 0.01f, 5), *bias = dalloc(LDMAX, 0.1f, 6);
     float *bd = dalloc(H, 0.f, 7);
     std::vector<Variant> vs;
     auto fwd_args = [&](GemmArgs &g, EpiArgs &e) {
@@ -71,14 +72,14 @@ int main(int argc, char **argv)
     };
     auto wg_args = [&](GemmArgs &g, EpiArgs &e) {
         memset(&g, 0, sizeof(g)); memset(&e, 0, sizeof(e));
-        g.A = Y; g.lda = LD; g.B = dX; g.ldb = LD; g.K = B;
+        g.A = Y; g.lda = LD; g.B = dX; g.ldb = LD; g.K = KW;
         e.C = W; e.ldc = LD; e.m_limit = H; e.n_limit = H; e.n_true = H; e.aux2 = D; e.ldaux2 = LD; e.alpha = 1.f;
         e.mom = 0.5f; e.c1 = 0.0f; e.wc = 0.f; e.ndiv = 256.f; e.bias_w = bias; e.bias_d = bd;
     };
     const double fl = 2.0 * B * H * H;
 #define FWD(BM, BN, BK, WM, WN, PF) vs.push_back({"fwd  " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); go<BM, BN, BK, WM, WN, true, false, EPI_FWD_HIDDEN, PF>(s, g, e, B, H, 0); }, fl})
 #define DGR(BM, BN, BK, WM, WN, PF) vs.push_back({"dgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); go<BM, BN, BK, WM, WN, true, true, EPI_DGRAD, PF>(s, g, e, B, H, 0); }, fl})
-#define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " grid" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, fl})
+#define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " grid" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, 2.0 * H * H * (double)KW})
     FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);
     FWD(64, 32, 64, 2, 1, 1); FWD(64, 32, 64, 2, 1, 2);
     FWD(32, 32, 64, 1, 1, 1); FWD(32, 32, 64, 1, 1, 2); FWD(32, 32, 128, 1, 1, 1);
