@@ -125,13 +125,22 @@ def main():
         eng.obj.fill_chunk_synthetic(chunk, 20260927 + rank)       # each rank holds its own shard of every bunch
         nb_chunk = chunk // BUNCH
         pos = 0
-        step_fn = dp.dp_step if os.environ.get("BENCH_DP_SERIAL") == "1" else dp.dp_step_overlapped
+        mode = os.environ.get("BENCH_DP_MODE", "pipeline")     # pipeline | overlapped | serial
+        if mode == "pipeline":
+            pipe = dp.DPPipeline(eng, dist)
+            step_fn = lambda e, d, f: pipe.step(f)
+            flush = pipe.flush
+        else:
+            step_fn = dp.dp_step if mode == "serial" else dp.dp_step_overlapped
+            flush = lambda: None
         for _ in range(args.warmup):
             step_fn(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
+        flush()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step_fn(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
+        flush()
         barrier()
         dt = time.perf_counter() - t0
         obj = eng.obj

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "bp_last_error", "bp_abi_version", "bp_build_target", "bp_create", "bp_destroy", "bp_train_chunk",
     "bp_cv_chunk", "bp_forward", "bp_get_weights", "bp_get_deltas", "bp_upload_chunk",
     "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident", "bp_grad_buffer",
-    "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_apply_update_layer", "bp_advance_step",
+    "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_dp_forward_layer", "bp_dp_dgrads", "bp_dp_wgrad_layer", "bp_apply_update_layer", "bp_advance_step",
     "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
 ]
 
@@ -84,6 +84,9 @@ def load_library(path=None):
     lib.bp_apply_update.argtypes = [hp]
     lib.bp_dp_forward.argtypes = [hp, C.c_int]
     lib.bp_dp_backward_layer.argtypes = [hp, C.c_int]
+    lib.bp_dp_forward_layer.argtypes = [hp, C.c_int, C.c_int]
+    lib.bp_dp_dgrads.argtypes = [hp]
+    lib.bp_dp_wgrad_layer.argtypes = [hp, C.c_int]
     lib.bp_apply_update_layer.argtypes = [hp, C.c_int]
     lib.bp_advance_step.argtypes = [hp]
     lib.bp_use_grad_buffer.argtypes = [hp, C.c_void_p, C.c_size_t]
@@ -228,6 +231,15 @@ class BP_GPU(object):
 
     def dp_forward(self, first_frame):
         self._check(self._lib.bp_dp_forward(self._h, int(first_frame)))
+
+    def dp_forward_layer(self, first_frame, layer):
+        self._check(self._lib.bp_dp_forward_layer(self._h, int(first_frame), int(layer)))
+
+    def dp_dgrads(self):
+        self._check(self._lib.bp_dp_dgrads(self._h))
+
+    def dp_wgrad_layer(self, layer):
+        self._check(self._lib.bp_dp_wgrad_layer(self._h, int(layer)))
 
     def dp_backward_layer(self, layer):
         self._check(self._lib.bp_dp_backward_layer(self._h, int(layer)))

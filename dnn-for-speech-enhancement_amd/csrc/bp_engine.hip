@@ -45,7 +45,7 @@ struct bp_handle {
     float *grad; size_t grad_floats; size_t g_off[BP_MAXLAYER], g_cnt[BP_MAXLAYER];
     float *host_out;             // pinned staging for CV outputs
     uint32_t step;               // bunches trained so far (dropout stream position)
-    int dp_first, dp_next_layer; // layer-by-layer data-parallel backward in progress
+    int dp_first, dp_next_layer, dp_fwd_next; // layer-by-layer data-parallel step in progress
     long mask_lo, mask_hi; uint32_t mask_step0;
     uint32_t th_vis, th_hid;
     hipEvent_t ev0, ev1; float last_ms; int last_bunches;
@@ -119,7 +119,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->cap = cfg->max_chunk_frames > 0 ? cfg->max_chunk_frames : BP_MAXCACHEFRAME;
     if (h->cap < h->B) h->cap = h->B;
     h->chunk_frames = 0;
-    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0; h->dp_first = 0; h->dp_next_layer = 0;
+    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0; h->dp_first = 0; h->dp_next_layer = 0; h->dp_fwd_next = 0;
     h->th_vis = cfg->dropoutflag == 1 ? drop_threshold(cfg->visible_omit) : 0u;
     h->th_hid = cfg->dropoutflag == 1 ? drop_threshold(cfg->hid_omit) : 0u;
     if (cfg->dropoutflag == 1 && (h->B % 4 != 0 || cfg->rank_frame_offset % 4 != 0)) {
@@ -544,19 +544,52 @@ static hipError_t dp_input(bp_handle *h, int first, const float **x0)
     return hipSuccess;
 }
 
-extern "C" int bp_dp_forward(bp_handle *h, int first_frame)
+extern "C" int bp_dp_forward_layer(bp_handle *h, int first_frame, int layer)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_forward_layer: layer out of range");
     if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
-        return fail(BP_ERR_ARG, "bp_dp_forward: bunch outside the resident chunk");
+        return fail(BP_ERR_ARG, "bp_dp_forward_layer: bunch outside the resident chunk");
+    if (layer != 1 && (h->dp_fwd_next != layer || h->dp_first != first_frame))
+        return fail(BP_ERR_STATE, "bp_dp_forward_layer: layers must be called 1 ... numlayers-1 for one bunch");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
     const float *x0;
     HIPCHK(dp_input(h, first_frame, &x0));
     const float *tg = h->targ + (size_t)first_frame * h->ld[h->L - 1];
-    for (int l = 1; l < h->L; ++l)
-        HIPCHK(launch_fwd(h, h->stream, l, h->B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
-    h->dp_first = first_frame; h->dp_next_layer = h->L - 1;
+    HIPCHK(launch_fwd(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], tg, nullptr, true, 1.0f));
+    h->dp_first = first_frame; h->dp_fwd_next = layer + 1;
+    h->dp_next_layer = (layer == h->L - 1) ? h->L - 1 : 0;     // backward may start after the output layer
+    return BP_OK;
+}
+
+extern "C" int bp_dp_forward(bp_handle *h, int first_frame)
+{
+    int r = BP_OK;
+    for (int l = 1; h && r == BP_OK && l < h->L; ++l) r = bp_dp_forward_layer(h, first_frame, l);
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    return r;
+}
+
+extern "C" int bp_dp_dgrads(bp_handle *h)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (h->dp_next_layer != h->L - 1) return fail(BP_ERR_STATE, "bp_dp_dgrads: run the forward of a bunch first");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (int l = h->L - 1; l >= 2; --l) HIPCHK(launch_dgrad(h, h->stream, l, h->B));
+    h->dp_next_layer = -1;                                     // wgrads may now come in any order
+    return BP_OK;
+}
+
+extern "C" int bp_dp_wgrad_layer(bp_handle *h, int layer)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_wgrad_layer: layer out of range");
+    if (h->dp_next_layer != -1) return fail(BP_ERR_STATE, "bp_dp_wgrad_layer: call bp_dp_dgrads first");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const float *x0;
+    HIPCHK(dp_input(h, h->dp_first, &x0));
+    HIPCHK(launch_wgrad(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], false));
     return BP_OK;
 }
 

@@ -53,6 +53,18 @@ class HipEngine(object):
     def advance(self):
         self.obj.advance_step()
 
+    # finer split for the cross-step pipeline
+    def forward_layer(self, first_frame, l):
+        self.obj.dp_forward_layer(first_frame, l)
+
+    def dgrads(self):
+        self.obj.dp_dgrads()
+
+    def wgrad_layer(self, l):
+        self.obj.dp_wgrad_layer(l)
+        off, cnt = self.segments[l - 1]
+        return self.grad[off:off + cnt]
+
 
 def dp_step(engine, dist, first_frame):
     """One data-parallel minibatch: local gradients -> all-reduce(SUM) -> identical update."""
@@ -78,6 +90,50 @@ def dp_step_overlapped(engine, dist, first_frame):
             w.wait()
         engine.update_layer(l)
     engine.advance()
+
+
+class DPPipeline(object):
+    """Data-parallel training with the exchange pipelined ACROSS steps.  Per bunch: forward
+    (layer by layer), every dgrad, then the weight gradients largest-first (layer 1 holds 40 % of
+    the bytes), each followed at once by its async all-reduce.  The update of layer l is applied
+    right before the NEXT bunch's forward of layer l, so the all-reduces of layers 2.. overlap the
+    next forward and only layer 1's is on the critical path.  Arithmetic is unchanged: every
+    forward/dgrad of a bunch sees weights that include all updates of the previous bunch, and
+    dgrads of a bunch never see its own updates (same as BP_GPU.cu:588-671).  Call flush() after
+    the last bunch."""
+
+    def __init__(self, engine, dist):
+        self.engine, self.dist = engine, dist
+        self.multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+        self.pending = None
+
+    def step(self, first_frame):
+        eng, L = self.engine, self.engine.nlayers
+        pend = self.pending
+        if pend is not None:
+            eng.advance()
+        for l in range(1, L):
+            if pend is not None:
+                if pend[l] is not None:
+                    pend[l].wait()
+                eng.update_layer(l)
+            eng.forward_layer(first_frame, l)
+        eng.dgrads()
+        self.pending = {}
+        for l in range(1, L):
+            seg = eng.wgrad_layer(l)
+            self.pending[l] = (self.dist.all_reduce(seg, op=self.dist.ReduceOp.SUM, async_op=True)
+                               if self.multi else None)
+
+    def flush(self):
+        if self.pending is None:
+            return
+        for l in range(1, self.engine.nlayers):
+            if self.pending[l] is not None:
+                self.pending[l].wait()
+            self.engine.update_layer(l)
+        self.engine.advance()
+        self.pending = None
 
 
 def shard_rows(n_frames, global_bunch, world, rank):

@@ -131,6 +131,13 @@ int bp_grads_resident(bp_handle *h, int first_frame);            /* one local bu
  * bp_apply_update   == every bp_apply_update_layer + bp_advance_step. */
 int bp_dp_forward(bp_handle *h, int first_frame);
 int bp_dp_backward_layer(bp_handle *h, int layer);
+/* Finer split for a cross-step pipeline (the exchange of a step overlaps the next step's forward):
+ * bp_dp_forward_layer for layer = 1 ... numlayers-1 (layer 1 names the bunch), bp_dp_dgrads (every
+ * dgrad, no weight gradient yet), then bp_dp_wgrad_layer in ANY order (all dgrads are done, so the
+ * largest segment can go first).  bp_dp_forward == every bp_dp_forward_layer. */
+int bp_dp_forward_layer(bp_handle *h, int first_frame, int layer);
+int bp_dp_dgrads(bp_handle *h);
+int bp_dp_wgrad_layer(bp_handle *h, int layer);
 int bp_apply_update_layer(bp_handle *h, int layer);
 int bp_advance_step(bp_handle *h);
 int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats);

@@ -50,10 +50,32 @@ class OracleEngine(object):
         return self.flat[off:off + cnt]
 
     def update_layer(self, l):
-        pass                                      # applied for all layers in advance()
+        if self._mode == "pipe":                  # keep this layer's summed segment; apply when all are in
+            off = sum(a + c for a, c in self.sizes[:l - 1]); cnt = sum(self.sizes[l - 1])
+            self._summed[off:off + cnt] = self.flat[off:off + cnt]
+            if l == len(LS) - 1:
+                self.flat.copy_(self._summed)
+                self.update()
 
     def advance(self):
-        self.update()
+        if self._mode != "pipe":
+            self.update()
+
+    # finer split used by DPPipeline
+    _mode = "layer"
+
+    def forward_layer(self, first_frame, l):
+        self._mode = "pipe"
+        self._first = first_frame
+        if not hasattr(self, "_summed"):
+            self._summed = self.torch.zeros_like(self.flat)
+
+    def dgrads(self):
+        self.grads(self._first)                   # every update of the previous bunch has been applied
+        self._stash = self.flat.clone()
+
+    def wgrad_layer(self, l):
+        return self.backward_layer(l)
 
     def update(self):
         g = self.flat.numpy()
@@ -84,14 +106,20 @@ def _worker(rank, port, q, overlapped):
     rows = dp.shard_rows(x.shape[0], BG, WORLD, rank)                  # this rank's slice of every bunch
     eng = OracleEngine(O, torch, W, b, x[rows], t[rows], WORLD)
     lb = BG // WORLD
-    for i in range(NB):
-        (dp.dp_step_overlapped if overlapped else dp.dp_step)(eng, dist, i * lb)
+    if overlapped == "pipeline":
+        pipe = dp.DPPipeline(eng, dist)
+        for i in range(NB):
+            pipe.step(i * lb)
+        pipe.flush()
+    else:
+        for i in range(NB):
+            (dp.dp_step_overlapped if overlapped else dp.dp_step)(eng, dist, i * lb)
     q.put((rank, [w.copy() for w in eng.o.W[1:]], [v.copy() for v in eng.o.b[1:]], rows[:4].tolist(), len(rows)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlapped", [False, True])
+@pytest.mark.parametrize("overlapped", [False, True, "pipeline"])
 def test_two_rank_gloo_matches_single_device(oracle_mod, overlapped):
     torch = pytest.importorskip("torch")
     import torch.multiprocessing as mp

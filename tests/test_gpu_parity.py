@@ -132,6 +132,28 @@ def test_dp_split_equals_fused_step(pkg, oracle_mod):
         assert np.array_equal(w2[l], ws[l]) and np.array_equal(b2[l], bs[l])
     with pytest.raises(pkg.BPError):
         s2.dp_backward_layer(1)                     # out of order: no forward in progress
+    # cross-step pipeline order: updates of bunch i-1 interleaved with the forward of bunch i,
+    # all dgrads, then weight gradients largest (layer 1) first
+    s3 = _mk(pkg, ls, B, W, b)
+    s3.upload_chunk(x, t)
+    L = len(ls)
+    for i in range(2):
+        if i:
+            s3.advance_step()
+        for l in range(1, L):
+            if i:
+                s3.apply_update_layer(l)
+            s3.dp_forward_layer(i * B, l)
+        s3.dp_dgrads()
+        for l in range(1, L):
+            s3.dp_wgrad_layer(l)
+    for l in range(1, L):
+        s3.apply_update_layer(l)
+    s3.advance_step()
+    w3, b3 = s3.get_weights()
+    for l in range(1, L):
+        assert np.array_equal(w3[l], ws[l]) and np.array_equal(b3[l], bs[l])
+    s3.close()
     a.close(); s.close(); s2.close()
     # two "ranks" on one GPU: shard gradients summed on the host == oracle on the global bunch
     Bg = 2 * B
