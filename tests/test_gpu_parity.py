@@ -185,3 +185,86 @@ def test_errors_are_reported_not_swallowed(pkg):
     with pytest.raises(pkg.BPError):
         g.train_resident(0, 4)                                                        # nothing resident
     g.close()
+
+
+# ---------------------------------------------------------------- BASELINE.json full-size configurations
+C2 = [257 * 11, 2048, 2048, 2048, 257]
+C3 = [257 * 12, 2048, 2048, 2048, 257]          # 11 frames + the appended noise-estimate block (NAT)
+
+
+@pytest.mark.parametrize("ls,drop", [(C2, True), (C3, False)])
+def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
+    """C2 / C3 at their real sizes (256-frame bunch): two SGD steps against the oracle."""
+    B = 256
+    W, b = N.glorot_net(ls, seed=1, beta=0.5)                       # the bench's init recipe
+    rng = np.random.default_rng(20260927)
+    x = rng.standard_normal((2 * B, ls[0]), dtype=np.float32)
+    t = rng.standard_normal((2 * B, ls[-1]), dtype=np.float32)
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=31) if drop else {}
+    g = _mk(pkg, ls, B, W, b, cap=2 * B, **kw)
+    o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, **kw)                      # fp32, reference summation order
+    o64 = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, acc_double=True, **kw)    # fp64 accumulation
+    assert relerr(g.forward(x[:300]), o.forward(x[:300])) < TOL                  # same weights: pure forward parity
+    g.train(2 * B, x, t)
+    assert o.train(x, t) == 2 and o64.train(x, t) == 2
+    w, bb = g.get_weights()
+    dw, dbb = g.get_deltas()
+
+    def close(a, r32, r64):
+        # 1e-4 relative, plus slack for quantities that are ill-conditioned in fp32 under ANY summation
+        # order: the bias gradient is a sum of 256 cancelling terms (biases start at 0 and stay ~1e-5),
+        # and at this size a handful of the 1.5 M hidden pre-activations per bunch sit within rounding of
+        # 0, so their ReLU on/off decision (hence one frame's contribution to a column of the ~1e-6
+        # momentum state) depends on the GEMM's summation order.  There the bar is "as close to the
+        # fp64-accumulated value as the fp32 restatement of the reference is"
+        ea = np.abs(np.asarray(a, np.float64) - r64).max()
+        e32 = np.abs(np.asarray(r32, np.float64) - r64).max()
+        return ea <= TOL * np.abs(r64).max() + 4.0 * e32
+
+    for l in range(1, len(ls)):
+        assert close(w[l], o.W[l], o64.W[l]) and relerr(w[l], o.W[l]) < 5 * TOL, l
+        assert close(dw[l], o.dW[l], o64.dW[l]), l
+        assert close(bb[l], o.b[l], o64.b[l]) and close(dbb[l], o.db[l], o64.db[l]), l
+    g.close()
+
+
+def test_full_size_properties(pkg):
+    """Size-independent properties on C2: (a) bit-reproducible for a fixed seed, (b) lrate 0 leaves
+    the weights untouched and the momentum state at zero, (c) the data-parallel split with the
+    gradients of 2 half-bunches summed equals (to fp32 summation order) the single-device step."""
+    ls, B = C2, 256
+    W, b = N.glorot_net(ls, seed=1, beta=0.5)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((B, ls[0]), dtype=np.float32)
+    t = rng.standard_normal((B, ls[-1]), dtype=np.float32)
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=77)
+    outs = []
+    for _ in range(2):
+        g = _mk(pkg, ls, B, W, b, cap=B, **kw)
+        g.train(B, x, t)
+        outs.append(g.get_weights())
+        g.close()
+    for l in range(1, len(ls)):
+        assert np.array_equal(outs[0][0][l], outs[1][0][l]) and np.array_equal(outs[0][1][l], outs[1][1][l])
+    z = _mk(pkg, ls, B, W, b, cap=B, lr=0.0, **kw)
+    z.train(B, x, t)
+    w, bb = z.get_weights(); dw, dbb = z.get_deltas()
+    for l in range(1, len(ls)):
+        assert np.array_equal(w[l], W[l]) and np.array_equal(bb[l], b[l])
+        assert not dw[l].any() and not dbb[l].any()
+    z.close()
+    # (c) no dropout so that the fused single-device step is the reference
+    a = _mk(pkg, ls, B, W, b, cap=B)
+    a.train(B, x, t)
+    wa, ba = a.get_weights(); a.close()
+    h = B // 2
+    r0 = _mk(pkg, ls, h, W, b, cap=h, global_bunchsize=B, rank_frame_offset=0, gpu_used=2)
+    r1 = _mk(pkg, ls, h, W, b, cap=h, global_bunchsize=B, rank_frame_offset=h, gpu_used=2)
+    r0.upload_chunk(x[:h], t[:h]); r1.upload_chunk(x[h:], t[h:])
+    r0.grads_resident(0); r1.grads_resident(0)
+    r0.write_grads(r0.read_grads() + r1.read_grads())
+    r0.apply_update()
+    w0, b0 = r0.get_weights()
+    for l in range(1, len(ls)):
+        assert relerr(w0[l], wa[l]) < 1e-5 and relerr(b0[l], ba[l]) < 1e-5
+    r0.close(); r1.close()
