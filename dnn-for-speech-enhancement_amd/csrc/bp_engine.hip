@@ -264,7 +264,9 @@ using KDgradWide = GemmKernel<32, 64, 64, 1, 2, true, true, EPI_DGRAD>;
 using KDgradNarrow = GemmKernel<32, 32, 64, 1, 1, true, true, EPI_DGRAD>;
 // wgrad 128x64 tiles: 25 % less operand traffic through L2 than 64x64 (measured 30.0 vs 33.8 us on
 // the 2048x2048 layer); a narrow output layer keeps 64x64 so that more workgroups exist
-template <int EPI> using KWgradWide = GemmKernel<128, 64, 16, 2, 2, false, false, EPI>;
+template <int EPI, int NT_S = 0> using KWgradWide = GemmKernel<128, 64, 16, 2, 2, false, false, EPI, 1, NT_S>;
+// bunch of 256 frames = 16 k-tiles: fully unrolled k-loop with the W/delta fetch spread over it
+using KWgradWide256 = KWgradWide<EPI_WGRAD_UPDATE, 16>;
 template <int EPI> using KWgradNarrow = GemmKernel<64, 64, 32, 2, 2, false, false, EPI>;
 
 // dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T)     (BP_GPU.cu:611-637)
@@ -316,8 +318,10 @@ static hipError_t run_single(hipStream_t st, Prepared p)
     switch (p.cfg) {
     case CFG_DGRAD_WIDE: return run_one<KDgradWide>(st, p, 32, 64);
     case CFG_DGRAD_NARROW: return run_one<KDgradNarrow>(st, p, 32, 32);
-    case CFG_WGRAD_WIDE: return p.fused ? run_one<KWgradWide<EPI_WGRAD_UPDATE>>(st, p, 128, 64)
-                                        : run_one<KWgradWide<EPI_WGRAD_STORE>>(st, p, 128, 64);
+    case CFG_WGRAD_WIDE:
+        if (p.fused && p.g.K == 256) return run_one<KWgradWide256>(st, p, 128, 64);
+        return p.fused ? run_one<KWgradWide<EPI_WGRAD_UPDATE>>(st, p, 128, 64)
+                       : run_one<KWgradWide<EPI_WGRAD_STORE>>(st, p, 128, 64);
     default: return p.fused ? run_one<KWgradNarrow<EPI_WGRAD_UPDATE>>(st, p, 64, 64)
                             : run_one<KWgradNarrow<EPI_WGRAD_STORE>>(st, p, 64, 64);
     }
@@ -358,7 +362,7 @@ static hipError_t run_pair(hipStream_t st, Prepared a, Prepared b, bool allow_du
 
 // Several wgrad problems in one grouped launch when they all use the wide configuration, else one
 // launch each.
-template <int EPI>
+template <class K>
 static hipError_t run_multi_wide(hipStream_t st, Prepared *ps, int n)
 {
     MultiArgs a; memset(&a, 0, sizeof(a));
@@ -369,14 +373,20 @@ static hipError_t run_multi_wide(hipStream_t st, Prepared *ps, int n)
         t += ps[i].g.tiles_m * ps[i].g.tiles_n;
     }
     a.first_tile[n] = t; a.n = n;
-    hipLaunchKernelGGL((bp_gemm_multi<KWgradWide<EPI>>), dim3(t), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((bp_gemm_multi<K>), dim3(t), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
 {
     bool wide = grouped && n >= 2 && n <= 4;
     for (int i = 0; i < n; ++i) wide = wide && ps[i].cfg == CFG_WGRAD_WIDE && ps[i].fused == ps[0].fused;
-    if (wide) return ps[0].fused ? run_multi_wide<EPI_WGRAD_UPDATE>(st, ps, n) : run_multi_wide<EPI_WGRAD_STORE>(st, ps, n);
+    if (wide) {
+        bool k256 = ps[0].fused;
+        for (int i = 0; i < n; ++i) k256 = k256 && ps[i].g.K == 256;
+        if (k256) return run_multi_wide<KWgradWide256>(st, ps, n);
+        return ps[0].fused ? run_multi_wide<KWgradWide<EPI_WGRAD_UPDATE>>(st, ps, n)
+                           : run_multi_wide<KWgradWide<EPI_WGRAD_STORE>>(st, ps, n);
+    }
     for (int i = 0; i < n; ++i) { hipError_t er = run_single(st, ps[i]); if (er != hipSuccess) return er; }
     return hipSuccess;
 }

@@ -47,6 +47,9 @@ struct GemmArgs {
     int lda, ldb;            // leading dimensions (floats)
     int K;                   // reduction extent actually looped (rounded up to BK inside)
     int tiles_m, tiles_n;
+#ifdef BP_TRACE              // development only: per-workgroup phase timestamps (tools/gemm_trace.hip)
+    unsigned long long *trace;
+#endif
     int k_split;             // split-K: workgroup row blockIdx.y handles k in [y*k_split, y*k_split + K)
     size_t slab_stride;      // split-K: floats between the partial-sum slabs of consecutive k-slices
 };
@@ -250,6 +253,18 @@ __device__ __forceinline__ void ksplit_take(f32x16 &acc, const float *red, int w
     }
 }
 
+// Pieces [LO, HI) of the epilogue-input fetch of a wave's TM x TN blocks; piece = (block i, j; 4-register
+// group q).  Lets the fully unrolled k-loop spread the fetch over its iterations.
+template <int EPI, int TM, int TN, int LO, int HI>
+__device__ __forceinline__ void epilogue_fetch_pieces(const EpiArgs &e, int mb0, int nb0, int lane, EpiPre (&pre)[TM][TN])
+{
+    if constexpr (LO < HI && LO < TM * TN * 4) {
+        constexpr int i = LO / (TN * 4), j = (LO / 4) % TN, q = LO % 4;
+        epilogue_fetch<EPI, 4 * q, 4>(e, mb0 + i * 32, nb0 + j * 32, lane, pre[i][j]);
+        epilogue_fetch_pieces<EPI, TM, TN, LO + 1, HI>(e, mb0, nb0, lane, pre);
+    }
+}
+
 // ------------------------------------------------------------------ the GEMM
 // Register image of one k-tile of both operands (global -> registers -> LDS staging).
 template <int NVA, int NVB>
@@ -442,9 +457,15 @@ struct GemmCfg {
 // The workgroup program of one GEMM problem: workgroups first_block, first_block+stride, ... of
 // the launch walk its tiles.  Wrapped by bp_gemm (one problem per launch) and bp_gemm_dual (two
 // independent problems in one launch, see there).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1>
+// NT_S > 0: the reduction is exactly NT_S k-tiles (host guarantees K == NT_S*BK) and the k-loop is
+// fully unrolled, which lets the W/delta fetch of the fused update be issued one piece per iteration
+// (static register indices).  Why: s_waitcnt vmcnt is in-order, so when all of it is issued up front
+// the very first operand-tile wait also waits for that whole burst (67 MB chip-wide for a 2048x2048
+// layer) -- the prologue of wgrad then takes 4.2 us instead of 1.3 us (in-kernel timestamps).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0>
 struct GemmKernel {
     using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
+    static constexpr bool STATIC_K = NT_S > 0 && PF == 1 && EPI == EPI_WGRAD_UPDATE && Cfg::KS == 1 && NT_S <= 32 && NT_S >= 4;
     static constexpr int KS = Cfg::KS, TM = Cfg::TM, TN = Cfg::TN;
     static constexpr int A_STAGE = Cfg::A_STAGE, B_STAGE = Cfg::B_STAGE, STAGE = A_STAGE + B_STAGE;
     static constexpr bool BIASG = Cfg::BIASG;
@@ -472,6 +493,12 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     // n-tiles so the W / dEdX column panels it streams stay in its private L2.
     // Persistent over tiles (grid may be smaller than the tile count): the epilogue's stores of
     // one tile are still draining while the next tile's k-loop runs.
+#ifdef BP_TRACE
+#define TRACE(i) do { if (tid == 0 && g.trace) g.trace[(size_t)first_block * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define TRACE(i) ((void)0)
+#endif
+    TRACE(0);
     for (int b = first_block; b < g.tiles_m * g.tiles_n; b += stride) {
     int tile_m, tile_n;
     {
@@ -508,7 +535,9 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     // hides under the k-loop (same lane->element map as the accumulator).
     EpiPre pre[TM][TN];
     const int mb0 = m0 + wm * TM * 32, nb0 = n0 + wn * TN * 32;
-    if constexpr (KS == 1) {
+    if constexpr (STATIC_K) {
+        // fetched piecewise inside the unrolled k-loop below
+    } else if constexpr (KS == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -545,12 +574,36 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     Cfg::load(r1, PA(1), PB(1), offs);
     if constexpr (PF >= 2) Cfg::load(r2, PA(2), PB(2), offs);
     __syncthreads();
+    TRACE(1);
     // Invariant at the top of iteration t: LDS stage t&1 holds tile t; tile t+1 (and t+2 when
     // PF == 2) are in flight / landed in registers.  The iteration multiplies tile t and, between
     // the MFMAs, issues the global loads of tile t+1+PF and moves tile t+1 into the other stage.
     // The steady-state loops contain no conditionals (a conditional step makes hipcc copy the
     // accumulators between register ranges every iteration); the last 1..PF+1 tiles run after.
     int t = 0, buf = 0;
+    if constexpr (STATIC_K) {
+        // fully unrolled: iteration T multiplies tile T (stage T&1), stores tile T+1, loads tile T+2 and then
+        // issues its share of the W/delta pieces -- younger than this iteration's tile loads, so the
+        // in-order wait for the next tile does not include it and it has ~2 iterations to land
+        constexpr int NPRE = TM * TN * 4, PER = (NPRE + NT_S - 4) / (NT_S - 3);
+#define SBODY(T)                                                                                               \
+        if constexpr ((T) < NT_S) {                                                                            \
+            if constexpr ((T) % 2 == 0)                                                                        \
+                Cfg::template step<((T) + 1 < NT_S), ((T) + 2 < NT_S)>(AS(0), BS(0), accs, ks, a_off, b_off, kh, r1, AS(1), BS(1), \
+                                                                     r0, PA((T) + 2), PB((T) + 2), offs, tid, bsum);    \
+            else                                                                                               \
+                Cfg::template step<((T) + 1 < NT_S), ((T) + 2 < NT_S)>(AS(1), BS(1), accs, ks, a_off, b_off, kh, r0, AS(0), BS(0), \
+                                                                     r1, PA((T) + 2), PB((T) + 2), offs, tid, bsum);    \
+            __syncthreads();                                                                                   \
+            epilogue_fetch_pieces<EPI, TM, TN, (T) * PER, ((T) + 1) * PER>(e, mb0, nb0, lane, pre);            \
+        }
+        SBODY(0) SBODY(1) SBODY(2) SBODY(3) SBODY(4) SBODY(5) SBODY(6) SBODY(7)
+        SBODY(8) SBODY(9) SBODY(10) SBODY(11) SBODY(12) SBODY(13) SBODY(14) SBODY(15)
+        SBODY(16) SBODY(17) SBODY(18) SBODY(19) SBODY(20) SBODY(21) SBODY(22) SBODY(23)
+        SBODY(24) SBODY(25) SBODY(26) SBODY(27) SBODY(28) SBODY(29) SBODY(30) SBODY(31)
+#undef SBODY
+        epilogue_fetch_pieces<EPI, TM, TN, NT_S * PER, NPRE>(e, mb0, nb0, lane, pre);   // (none left when PER covers all)
+    } else
     if constexpr (PF == 1) {
         // tile t+1 in r1 (even t) / r0 (odd t)
         for (; t + 3 <= nt; t += 2) {
@@ -587,8 +640,11 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
             }
         }
     }
-    STEP(false, false, buf, r0, r0, 0);        // last tile: nothing left to stage or fetch
-    __syncthreads();
+    if constexpr (!STATIC_K) {
+        STEP(false, false, buf, r0, r0, 0);    // last tile: nothing left to stage or fetch
+        __syncthreads();
+    }
+    TRACE(2);
 #undef K0_OF
 #undef PA
 #undef PB
@@ -665,13 +721,15 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     }
     if (b + stride < g.tiles_m * g.tiles_n) __syncthreads();   // smem is reused by the next tile
     }   // tile loop
+    TRACE(3);
+#undef TRACE
 }
 };   // GemmKernel
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1>
-__global__ __launch_bounds__(256) void bp_gemm(const GemmArgs g, const EpiArgs e)
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0>
+__global__ __launch_bounds__(256, 2) void bp_gemm(const GemmArgs g, const EpiArgs e)
 {
-    using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
+    using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>;
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     K::run(g, e, blockIdx.x, gridDim.x, blockIdx.y, smem);
 }
@@ -689,7 +747,7 @@ struct MultiArgs {
     int n;
 };
 template <class K>
-__global__ __launch_bounds__(256) void bp_gemm_multi(const MultiArgs a)
+__global__ __launch_bounds__(256, 2) void bp_gemm_multi(const MultiArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     const int b = blockIdx.x;
@@ -702,7 +760,7 @@ __global__ __launch_bounds__(256) void bp_gemm_multi(const MultiArgs a)
 // (e.g. the backward pair {dgrad(l-1), wgrad+update(l)}, which both only need dEdX_l).  Opt-in:
 // on MI355X it measured 1.5 % slower than the two launches back to back.
 template <class KA, class KB>
-__global__ __launch_bounds__(256) void bp_gemm_dual(const GemmArgs gA, const EpiArgs eA, const GemmArgs gB,
+__global__ __launch_bounds__(256, 2) void bp_gemm_dual(const GemmArgs gA, const EpiArgs eA, const GemmArgs gB,
                                                     const EpiArgs eB, int nA)
 {
     constexpr int SM = KA::SMEM > KB::SMEM ? KA::SMEM : KB::SMEM;

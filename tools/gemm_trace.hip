@@ -1,0 +1,59 @@
+// tools/gemm_trace.hip -- development probe: per-workgroup phase timestamps (100 MHz wall clock) of
+// back-to-back bp_gemm launches: entry, end of prologue, end of k-loop, end of epilogue.
+// usage: gemm_trace fwd|wgrad [K]
+#define BP_TRACE 1
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../dnn-for-speech-enhancement_amd/csrc/bp_kernels.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+static float *dalloc(size_t n) { float *d; CK(hipMalloc(&d, n * 4 + 65536)); CK(hipMemset(d, 0, n * 4 + 65536)); return d; }
+int main(int argc, char **argv)
+{
+    const bool wgrad = argc > 1 && !strcmp(argv[1], "wgrad");
+    const int B = 256, H = 2048, K = argc > 2 ? atoi(argv[2]) : (wgrad ? 256 : 2048);
+    float *Y = dalloc((size_t)2048 * H), *W = dalloc((size_t)H * H), *D = dalloc((size_t)H * H), *Yo = dalloc((size_t)2048 * H), *bias = dalloc(H), *bd = dalloc(H);
+    const int NWG = wgrad ? 512 : 256;
+    unsigned long long *tr; CK(hipMalloc(&tr, (size_t)NWG * 8 * 8 * 4)); CK(hipMemset(tr, 0, (size_t)NWG * 8 * 8 * 4));
+    GemmArgs g; EpiArgs e; memset(&g, 0, sizeof(g)); memset(&e, 0, sizeof(e));
+    e.alpha = 1.f;
+    if (wgrad) {
+        g.A = Y; g.lda = H; g.B = Yo; g.ldb = H; g.K = K; g.tiles_m = 16; g.tiles_n = 32;
+        e.C = W; e.ldc = H; e.m_limit = H; e.n_limit = H; e.n_true = H; e.aux2 = D; e.ldaux2 = H; e.mom = 0.5f; e.ndiv = 256.f; e.bias_w = bias; e.bias_d = bd;
+    } else {
+        g.A = Y; g.lda = H; g.B = W; g.ldb = H; g.K = K; g.tiles_m = 8; g.tiles_n = 32;
+        e.C = Yo; e.ldc = H; e.m_limit = B; e.n_limit = H; e.n_true = H; e.bias = bias; e.drop_thresh = 858993459u;
+    }
+    hipStream_t st; CK(hipStreamCreate(&st));
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int l = 0; l < 4; ++l) {
+            g.trace = tr + (size_t)l * NWG * 8;
+            if (wgrad && K == 256 && argc > 3) hipLaunchKernelGGL((bp_gemm<128, 64, 16, 2, 2, false, false, EPI_WGRAD_UPDATE, 1, 16>), dim3(NWG), dim3(256), 0, st, g, e);
+            else if (wgrad) hipLaunchKernelGGL((bp_gemm<128, 64, 16, 2, 2, false, false, EPI_WGRAD_UPDATE, 1>), dim3(NWG), dim3(256), 0, st, g, e);
+            else hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>), dim3(NWG), dim3(256), 0, st, g, e);
+        }
+        CK(hipStreamSynchronize(st));
+    }
+    std::vector<unsigned long long> h((size_t)NWG * 8 * 4);
+    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int l = 0; l < 4; ++l) for (int b = 0; b < NWG; ++b) t0 = std::min(t0, h[((size_t)l * NWG + b) * 8]);
+    for (int l = 1; l < 4; ++l) {
+        double mn[4] = {1e30, 1e30, 1e30, 1e30}, mx[4] = {0, 0, 0, 0}, av[4] = {0, 0, 0, 0};
+        double dur[3] = {0, 0, 0};
+        for (int b = 0; b < NWG; ++b) {
+            double t[4];
+            for (int i = 0; i < 4; ++i) {
+                t[i] = (h[((size_t)l * NWG + b) * 8 + i] - t0) * 0.01;   // us
+                mn[i] = std::min(mn[i], t[i]); mx[i] = std::max(mx[i], t[i]); av[i] += t[i] / NWG;
+            }
+            for (int i = 0; i < 3; ++i) dur[i] += (t[i + 1] - t[i]) / NWG;
+        }
+        printf("launch %d (%s K=%d): entry [%.2f..%.2f] prologue_done [%.2f..%.2f] loop_done [%.2f..%.2f] end [%.2f..%.2f] us | per-WG avg: prologue %.2f loop %.2f epilogue %.2f\n",
+               l, wgrad ? "wgrad 128x64x16" : "fwd 32x64x64", K, mn[0], mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3], dur[0], dur[1], dur[2]);
+    }
+    return 0;
+}
