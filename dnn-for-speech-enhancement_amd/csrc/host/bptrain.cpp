@@ -1,0 +1,199 @@
+// bptrain.cpp -- command-line compatible replacement of the reference executable `BPtrain`
+// ("next" row N2 of SURVEY.md 8f): same `name=value` arguments (Interface.cc:89-244), same log lines,
+// same weight-file bytes, one epoch = train over the chunks of train_sent_range in shuffled order,
+// save weights, cross-validate over cv_sent_range (BPtrain.cc:16-101).  The trainer behind it is the
+// MI355X library through the drop-in class include/BP_GPU.h; the Perl epoch driver
+// (finetune_DNN_speech_enhancement_dropout_NAT.pl) can call this binary unchanged.
+//
+// Extra optional keys (defaults = live reference behaviour): activation=relu|sigmoid,
+// momentum_rule=live|classic, seed=<u64> (dropout stream), device=<ordinal>.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <string>
+#include <vector>
+
+#include "../../../include/BP_GPU.h"
+#include "pfile_reader.h"
+#include "wts_io.h"
+
+struct Params {
+    std::string fea_file, norm_file, targ_file, outwts_file, log_file, initwts_file, train_range, cv_range;
+    int fea_dim = 0, fea_context = 0, targ_offset = 0, dropoutflag = 0, traincache = 0, bunchsize = 0, gpu_used = 1;
+    int seed = 0, numlayers = 0, layersizes[MAXLAYER] = {0};
+    float momentum = 0, weightcost = 0, lrate = 0, visible_omit = 0, hid_omit = 0;
+    float wmin = -0.1f, wmax = 0.1f, bmin = -0.1f, bmax = 0.1f;          // Interface.cc:79-82
+};
+
+static void parse_range(const std::string &r, int *st, int *en, FILE *log)
+{
+    const size_t p = r.find('-');
+    if (p == std::string::npos) { fprintf(log, "sent range: %s format error.\n", r.c_str()); exit(0); }
+    *st = atoi(r.substr(0, p).c_str());
+    *en = atoi(r.substr(p + 1).c_str());
+}
+
+static void rand_weight(float *v, float mn, float mx, size_t n)        // Interface::GetRandWeight, Interface.cc:1036-1042
+{
+    for (size_t i = 0; i < n; ++i) v[i] = drand48() * (mx - mn) + mn;
+}
+
+int main(int argc, char **argv)
+{
+    const double t_start = (double)time(NULL);
+    Params P;
+    for (int i = 1; i < argc; ++i) {
+        char *eq = strchr(argv[i], '=');
+        if (!eq) { printf("Arg: %s  Format Error\n", argv[i]); exit(0); }
+        const std::string k(argv[i], eq - argv[i]), v(eq + 1);
+        if (k == "fea_file") P.fea_file = v; else if (k == "norm_file") P.norm_file = v;
+        else if (k == "targ_file") P.targ_file = v; else if (k == "outwts_file") P.outwts_file = v;
+        else if (k == "log_file") P.log_file = v; else if (k == "initwts_file") P.initwts_file = v;
+        else if (k == "train_sent_range") P.train_range = v; else if (k == "cv_sent_range") P.cv_range = v;
+        else if (k == "fea_dim") P.fea_dim = atoi(v.c_str()); else if (k == "fea_context") P.fea_context = atoi(v.c_str());
+        else if (k == "targ_offset") P.targ_offset = atoi(v.c_str()); else if (k == "dropoutflag") P.dropoutflag = atoi(v.c_str());
+        else if (k == "traincache") P.traincache = atoi(v.c_str()); else if (k == "bunchsize") P.bunchsize = atoi(v.c_str());
+        else if (k == "gpu_used") P.gpu_used = atoi(v.c_str()); else if (k == "init_randem_seed") P.seed = atoi(v.c_str());
+        else if (k == "momentum") P.momentum = (float)atof(v.c_str()); else if (k == "weightcost") P.weightcost = (float)atof(v.c_str());
+        else if (k == "lrate") P.lrate = (float)atof(v.c_str()); else if (k == "visible_omit") P.visible_omit = (float)atof(v.c_str());
+        else if (k == "hid_omit") P.hid_omit = (float)atof(v.c_str());
+        else if (k == "init_randem_weight_min") P.wmin = (float)atof(v.c_str()); else if (k == "init_randem_weight_max") P.wmax = (float)atof(v.c_str());
+        else if (k == "init_randem_bias_min") P.bmin = (float)atof(v.c_str()); else if (k == "init_randem_bias_max") P.bmax = (float)atof(v.c_str());
+        else if (k == "layersizes") {
+            P.numlayers = 0;
+            size_t pos = 0;
+            while (P.numlayers < MAXLAYER) {
+                const size_t c = v.find(',', pos);
+                P.layersizes[P.numlayers++] = atoi(v.substr(pos, c == std::string::npos ? c : c - pos).c_str());
+                if (c == std::string::npos) break;
+                pos = c + 1;
+            }
+        }
+        // switches the reference only has as source edits (forwarded to the shim through its environment keys)
+        else if (k == "activation") setenv("BP_ACTIVATION", v.c_str(), 1);
+        else if (k == "momentum_rule") setenv("BP_MOMENTUM_RULE", v.c_str(), 1);
+        else if (k == "seed") setenv("BP_SEED", v.c_str(), 1);
+        else if (k == "device") setenv("BP_DEVICE", v.c_str(), 1);
+        // unknown names are silently ignored, as in the reference (e.g. the .pl passes numlayers=)
+    }
+    FILE *log = fopen(P.log_file.c_str(), "wt");
+    if (!log) { printf("can not open output log file: %s\n", P.log_file.c_str()); exit(0); }
+    FILE *fp_out = fopen(P.outwts_file.c_str(), "wb");
+    if (!fp_out) { fprintf(log, "can not open output weights file: %s\n", P.outwts_file.c_str()); exit(0); }
+    const int L = P.numlayers;
+    if (L < 2 || L > MAXLAYER - 1) { fprintf(log, "layersizes: need 2..%d layer sizes\n", MAXLAYER - 1); exit(0); }
+    // parameter echo (Interface.cc:267-298)
+    fprintf(log, "parameters input:\n");
+    fprintf(log, "fea_file:             %s\n", P.fea_file.c_str());
+    fprintf(log, "norm_file:            %s\n", P.norm_file.c_str());
+    fprintf(log, "targ_file:            %s\n", P.targ_file.c_str());
+    fprintf(log, "outwts_file:          %s\n", P.outwts_file.c_str());
+    fprintf(log, "log_file:\t\t          %s\n", P.log_file.c_str());
+    fprintf(log, "initwts_file:         %s\n", P.initwts_file.c_str());
+    fprintf(log, "train_sent_range:     %s\n", P.train_range.c_str());
+    fprintf(log, "cv_sent_range:        %s\n", P.cv_range.c_str());
+    fprintf(log, "fea_dim:\t\t          %d\n", P.fea_dim);
+    fprintf(log, "fea_context:\t\t      %d\n", P.fea_context);
+    fprintf(log, "bunchsize:\t\t        %d\n", P.bunchsize);
+    fprintf(log, "gpu_used:\t\t          %d\n", P.gpu_used);
+    fprintf(log, "train_cache:\t\t      %d\n", P.traincache);
+    fprintf(log, "init_randem_seed:\t\t  %d\n", P.seed);
+    fprintf(log, "targ_offset:\t\t      %d\n", P.targ_offset);
+    fprintf(log, "dropoutflag:\t\t      %d\n", P.dropoutflag);
+    fprintf(log, "init_randem_weight_max:\t\t  %f\n", P.wmax);
+    fprintf(log, "init_randem_weight_min:\t\t  %f\n", P.wmin);
+    fprintf(log, "init_randem_bias_max:\t\t    %f\n", P.bmax);
+    fprintf(log, "init_randem_bias_min:\t\t    %f\n", P.bmin);
+    fprintf(log, "momentum:\t\t                %f\n", P.momentum);
+    fprintf(log, "weightcost:\t\t              %f\n", P.weightcost);
+    fprintf(log, "learnrate:\t\t              %f\n", P.lrate);
+    fprintf(log, "visible_omit:\t\t      %f\n", P.visible_omit);
+    fprintf(log, "hid_omit:\t\t      %f\n", P.hid_omit);
+    fprintf(log, "layersizes:\t\t              ");
+    for (int j = 0; j < L; ++j) fprintf(log, "%d,", P.layersizes[j]);
+    fprintf(log, "\nPlease check...\n");
+
+    bp::ReaderConfig rc;
+    rc.fea_file = P.fea_file; rc.targ_file = P.targ_file; rc.norm_file = P.norm_file;
+    rc.fea_dim = P.fea_dim; rc.fea_context = P.fea_context; rc.targ_offset = P.targ_offset;
+    rc.out_dim = P.layersizes[L - 1]; rc.traincache = P.traincache; rc.input_dim = P.layersizes[0];
+    if (P.traincache < 1 || P.traincache > MAXCACHEFRAME) { fprintf(log, "traincache must be in 1..%d\n", MAXCACHEFRAME); exit(0); }
+    bp::PfileReader reader(rc);
+    fprintf(log, "Loading Norm file...\n");
+    reader.open();
+    fprintf(log, "Norm file loaded.\n");
+
+    std::vector<std::vector<float>> Wv(L), Bv(L);
+    float *weights[MAXLAYER] = {0}, *bias[MAXLAYER] = {0};
+    for (int i = 1; i < L; ++i) {
+        Wv[i].assign((size_t)P.layersizes[i] * P.layersizes[i - 1], 0.f); Bv[i].assign(P.layersizes[i], 0.f);
+        weights[i] = Wv[i].data(); bias[i] = Bv[i].data();
+    }
+    srand48(P.seed);                                    // once, for weights and every shuffle (Interface.cc:338)
+    if (P.initwts_file.empty()) {
+        fprintf(log, "Getting Randemed initial weights...\n");
+        for (int i = 1; i < L; ++i) {
+            rand_weight(weights[i], P.wmin, P.wmax, Wv[i].size());
+            rand_weight(bias[i], P.bmin, P.bmax, Bv[i].size());
+        }
+        fprintf(log, "Randemed initial weights getted.\n");
+    } else {
+        FILE *fi = fopen(P.initwts_file.c_str(), "rb");
+        if (!fi) { fprintf(log, "can not open initial weights file: %s\n", P.initwts_file.c_str()); exit(0); }
+        fprintf(log, "Loading Init weight file...\n");
+        const std::string err = bp::read_weights(fi, L, P.layersizes, weights, bias);
+        fclose(fi);
+        if (!err.empty()) { fprintf(log, "%s\n", err.c_str()); exit(0); }
+        fprintf(log, "Init weight file loaded.\n");
+    }
+    fflush(log);
+    std::vector<float> indata((size_t)P.layersizes[0] * P.traincache), targ((size_t)P.layersizes[L - 1] * P.traincache);
+
+    // ---- BPtrain.cc:31-96
+    BP_GPU *TrainObj = new BP_GPU(P.gpu_used, L, P.layersizes, P.bunchsize, P.lrate, P.momentum, P.weightcost, weights, bias,
+                                  P.dropoutflag, P.visible_omit, P.hid_omit);
+    fprintf(log, "Get pfile info over: Training data has %u frames, %u sentences.\n", reader.total_frames(), reader.total_sents());
+    int st, en;
+    parse_range(P.train_range, &st, &en, log);
+    const bp::PfileReader::Plan tp = reader.plan(st, en);
+    const int nchunks = (int)tp.chunk_frame_st.size();
+    fprintf(log, "Get chunk info over: Training sentences have %d chunks, %d samples.\n", nchunks, (int)tp.total_samples);
+    std::vector<int> chunk_index(nchunks);
+    for (int i = 0; i < nchunks; ++i) chunk_index[i] = i;
+    bp::PfileReader::rand_index(chunk_index.data(), nchunks);           // BPtrain.cc:47
+    for (int i = 0; i < nchunks; ++i) {
+        const int n = reader.read_chunk(tp, chunk_index[i], true, indata.data(), targ.data());
+        fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, n);
+        fflush(log);
+        TrainObj->train(n, indata.data(), targ.data());    // returns once the chunk is on the device: the next
+    }                                                      // Readchunk overlaps the GPU's work on this one
+    printf("begin to write weights\n");
+    TrainObj->returnWeights(weights, bias);
+    fprintf(log, "Saving weights to file...\n");
+    bp::write_weights(fp_out, L, P.layersizes, weights, bias);
+    fclose(fp_out);
+    fprintf(log, "Saving over.\n");
+    printf("finish to write weights\n\n");
+
+    printf("begin to CV\n");
+    fprintf(log, "Starting CV.\n");
+    parse_range(P.cv_range, &st, &en, log);
+    const bp::PfileReader::Plan cp = reader.plan(st, en);
+    fprintf(log, "Get cv chunk info over: CV sentences have %d chunks, %d samples.\n", (int)cp.chunk_frame_st.size(), (int)cp.total_samples);
+    float squared_err = 0.0f;
+    for (int i = 0; i < (int)cp.chunk_frame_st.size(); ++i) {
+        const int n = reader.read_chunk(cp, i, false, indata.data(), targ.data());
+        printf("cur_chunk_samples=%d\n", n);
+        squared_err += TrainObj->CrossValid(n, indata.data(), targ.data());
+    }
+    const float cvacc = squared_err / cp.total_samples;                  // BPtrain.cc:84
+    fprintf(log, "CV over. squared error: %f\n", cvacc);
+    fflush(log);
+    fprintf(log, "Total cost time: %.1f s.\n", (double)time(NULL) - t_start);
+    printf("all finish!\n");
+    delete TrainObj;
+    fclose(log);
+    return 1;                                                            // BPtrain.cc:100
+}

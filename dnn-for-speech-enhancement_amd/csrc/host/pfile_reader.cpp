@@ -1,0 +1,211 @@
+#include "pfile_reader.h"
+
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace bp {
+
+static const long PFILE_HEADER_SIZE = 32768;   // Interface.cc:13
+
+void die(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vprintf(fmt, ap);
+    va_end(ap);
+    printf("\n");
+    exit(0);                                    // reference convention (Interface.cc:246-265)
+}
+
+static inline uint32_t bswap(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
+
+static unsigned header_uint(const char *hdr, const char *key)     // Interface::get_uint, Interface.cc:1057-1075
+{
+    const char *p = strstr(hdr, key);
+    if (!p) die("pfile header format is Not correct.");
+    p += strlen(key);
+    unsigned v = 0; int count = 0;
+    sscanf(p, " %u%n", &v, &count);
+    if (count <= 1) die("%s num in pfile header is Not correct.", key);
+    return v;
+}
+
+// Interface::read_tail (Interface.cc:1077-1093): the table holds num_sentences+1 big-endian cumulative
+// frame offsets; the first word is skipped, out[i] = frames before the END of sentence i.
+static void read_tail(FILE *fp, long offset, unsigned nsent, std::vector<int> &out)
+{
+    out.resize(nsent);
+    if (fseek(fp, offset + 4, SEEK_SET) != 0 || fread(out.data(), sizeof(int), nsent, fp) != nsent)
+        die("pfile tail is Not correct.");
+    for (unsigned i = 0; i < nsent; ++i) out[i] = (int)bswap((uint32_t)out[i]);
+}
+
+PfileReader::PfileReader(const ReaderConfig &cfg) : cfg_(cfg)
+{
+    // the reference demands layersizes[0] == fea_dim*ctx + fea_dim (NAT hard-wired, Interface.cc:395-399); the
+    // original check fea_dim*ctx is kept as the NAT-off mode
+    if (cfg_.input_dim == cfg_.fea_dim * (cfg_.fea_context + 1)) nat_ = true;
+    else if (cfg_.input_dim == cfg_.fea_dim * cfg_.fea_context) nat_ = false;
+    else die("feadim times (+ noise) context must be equal to layersizes[0]");
+}
+
+PfileReader::~PfileReader()
+{
+    if (fp_data_) fclose(fp_data_);
+    if (fp_targ_) fclose(fp_targ_);
+}
+
+void PfileReader::open()
+{
+    if (!(fp_data_ = fopen(cfg_.fea_file.c_str(), "rb"))) die("can not open feature file: %s", cfg_.fea_file.c_str());
+    if (!(fp_targ_ = fopen(cfg_.targ_file.c_str(), "rb"))) die("can not open target file: %s", cfg_.targ_file.c_str());
+    // normalisation file: 1 header line, fea_dim means, 1 header line, fea_dim inverse std (Interface.cc:300-325)
+    FILE *fn = fopen(cfg_.norm_file.c_str(), "rt");
+    if (!fn) die("can not open normalization file: %s", cfg_.norm_file.c_str());
+    char buff[1024];
+    mean_.resize(cfg_.fea_dim); dvar_.resize(cfg_.fea_dim);
+    if (!fgets(buff, sizeof(buff), fn)) die("normalization file too short");
+    for (int j = 0; j < cfg_.fea_dim; ++j) { if (!fgets(buff, sizeof(buff), fn)) die("normalization file too short"); mean_[j] = (float)atof(buff); }
+    if (!fgets(buff, sizeof(buff), fn)) die("normalization file too short");
+    for (int j = 0; j < cfg_.fea_dim; ++j) { if (!fgets(buff, sizeof(buff), fn)) die("normalization file too short"); dvar_[j] = (float)atof(buff); }
+    fclose(fn);
+
+    std::vector<char> header(PFILE_HEADER_SIZE + 1, 0);
+    if (fread(header.data(), PFILE_HEADER_SIZE, 1, fp_data_) != 1) die("Failed to read data pfile header.");
+    total_sents_ = header_uint(header.data(), "-num_sentences");
+    total_frames_ = header_uint(header.data(), "-num_frames");
+    read_tail(fp_data_, (long)total_frames_ * (long)sizeof(float) * (2 + cfg_.fea_dim) + PFILE_HEADER_SIZE, total_sents_,
+              frames_before_sent_);
+    if (fseek(fp_targ_, 0, SEEK_SET) != 0 || fread(header.data(), PFILE_HEADER_SIZE, 1, fp_targ_) != 1)
+        die("Failed to read target pfile header.");
+    const unsigned ts = header_uint(header.data(), "-num_sentences"), tf = header_uint(header.data(), "-num_frames");
+    if (ts != total_sents_ || tf != total_frames_)
+        die("frames or sentence num in target pfile and data pfile is not consistent.");
+    std::vector<int> ttail;
+    read_tail(fp_targ_, (long)tf * (long)sizeof(float) * (2 + cfg_.out_dim) + PFILE_HEADER_SIZE, ts, ttail);
+    for (unsigned i = 0; i < total_sents_; ++i)
+        if (ttail[i] != frames_before_sent_[i]) die("tails in target pfile and data pfile is not consistent---%u.", i);
+}
+
+PfileReader::Plan PfileReader::plan(int sent_st, int sent_en) const
+{
+    if (sent_en < sent_st || sent_st < 0 || sent_en >= (int)total_sents_)
+        die("sent range: %d to %d number error.", sent_st, sent_en);
+    Plan p; p.sent_st = sent_st; p.sent_en = sent_en;
+    const int ctx = cfg_.fea_context, cache = cfg_.traincache;
+    int cur_frame_id = sent_st == 0 ? 0 : frames_before_sent_[sent_st - 1];
+    int cur_chunk_frames = 0;
+    p.chunk_frame_st.push_back(cur_frame_id);
+    for (int s = sent_st; s <= sent_en; ++s) {
+        const int frames_inc = frames_before_sent_[s] - cur_frame_id;
+        cur_frame_id = frames_before_sent_[s];
+        const int lost = frames_inc >= ctx ? ctx - 1 : frames_inc;       // a sentence loses ctx-1 frames to stacking
+        cur_chunk_frames += frames_inc - lost;
+        while (cur_chunk_frames >= cache) {
+            // the next chunk starts where the cache-th sample of this one ended; the samples that would
+            // straddle the cut are lost (Interface.cc:607-614)
+            const int next_st = cur_frame_id - (cur_chunk_frames - cache);
+            if (next_st >= (int)total_frames_) { cur_chunk_frames = cache - 1; break; }   // (the reference would spin here)
+            p.chunk_frame_st.push_back(next_st);
+            cur_chunk_frames = (cur_frame_id - next_st > ctx - 1) ? (cur_frame_id - next_st - ctx + 1) : 0;
+        }
+    }
+    p.total_samples = (unsigned)((p.chunk_frame_st.size() - 1) * (size_t)cache + cur_chunk_frames);
+    return p;
+}
+
+void PfileReader::rand_index(int *vec, int len)
+{
+    for (int i = 0; i < len - 1; ++i) {
+        const int idx = (int)(lrand48() % (len - i));
+        const int tmp = vec[idx];
+        vec[idx] = vec[len - 1 - i];
+        vec[len - 1 - i] = tmp;
+    }
+}
+
+int PfileReader::read_chunk(const Plan &p, int ci, bool shuffle, float *in, float *targ)
+{
+    const int D = cfg_.fea_dim, ctx = cfg_.fea_context, OD = cfg_.out_dim, s0 = cfg_.input_dim;
+    const int nchunks = (int)p.chunk_frame_st.size();
+    const int frame_st = p.chunk_frame_st[ci];
+    int frames_need, samples;
+    if (ci == nchunks - 1) {
+        frames_need = frames_before_sent_[p.sent_en] - frame_st;
+        samples = (int)p.total_samples - cfg_.traincache * ci;
+    } else {
+        frames_need = p.chunk_frame_st[ci + 1] - frame_st;
+        samples = cfg_.traincache;
+    }
+    std::vector<int> sample_index(samples > 0 ? samples : 0);
+    for (int i = 0; i < samples; ++i) sample_index[i] = i;
+    if (shuffle) rand_index(sample_index.data(), samples);
+    if (frames_need <= 0 || samples <= 0) return samples > 0 ? samples : 0;
+
+    // ---- features: big-endian records {sent_id, frame_id, feat[D]} -> mean/variance normalised floats
+    std::vector<uint32_t> raw((size_t)frames_need * (D + 2));
+    if (fseek(fp_data_, PFILE_HEADER_SIZE + (long)frame_st * (long)sizeof(float) * (D + 2), SEEK_SET) != 0)
+        die("data pfile cannot fseek to chunk %d.", ci);
+    if (fread(raw.data(), sizeof(float) * (D + 2), frames_need, fp_data_) != (size_t)frames_need)
+        die("data pfile: short read in chunk %d.", ci);
+    const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
+    std::vector<float> fea((size_t)frames_need * D);
+    for (int i = 0; i < frames_need; ++i)
+        for (int j = 0; j < D; ++j) {
+            const uint32_t w = bswap(raw[(size_t)i * (D + 2) + 2 + j]);
+            float v; memcpy(&v, &w, 4);
+            v -= mean_[j];
+            v *= dvar_[j];
+            fea[(size_t)i * D + j] = v;
+        }
+    // ---- targets (not normalised, Interface.cc:815-816)
+    std::vector<float> tg((size_t)frames_need * OD);
+    if (fseek(fp_targ_, PFILE_HEADER_SIZE + (long)frame_st * (long)sizeof(float) * (OD + 2), SEEK_SET) != 0)
+        die("targ pfile cannot fseek to chunk %d.", ci);
+    raw.resize((size_t)frames_need * (OD + 2));
+    if (fread(raw.data(), sizeof(float) * (OD + 2), frames_need, fp_targ_) != (size_t)frames_need)
+        die("targ pfile: short read in chunk %d.", ci);
+    for (int i = 0; i < frames_need; ++i)
+        for (int j = 0; j < OD; ++j) {
+            const uint32_t w = bswap(raw[(size_t)i * (OD + 2) + 2 + j]);
+            memcpy(&tg[(size_t)i * OD + j], &w, 4);
+        }
+
+    // ---- samples: per sentence segment inside the chunk, ctx stacked frames (oldest first) [+ NAT block]
+    int frames_processed = 0, cur_frame_id = frame_st, cur_sample = 0, cur_sent = first_sent;
+    while (frames_processed != frames_need && cur_sent < (int)total_sents_) {
+        int seg;
+        if (frames_before_sent_[cur_sent] > frames_need + frame_st) seg = frames_need - frames_processed;
+        else seg = frames_before_sent_[cur_sent] - cur_frame_id;
+        for (int j = 0; j <= seg - ctx && cur_sample < samples; ++j) {
+            float *row = in + (size_t)sample_index[cur_sample] * s0;
+            for (int i = 0; i < ctx; ++i)
+                memcpy(row + (size_t)i * D, &fea[(size_t)(frames_processed + j + i) * D], sizeof(float) * D);
+            if (nat_) {
+                // noise-aware training: mean of the segment's first 6 normalised frames, summed left to right
+                // and divided by 6.0f (Interface.cc:776-779, generalised from the literal 129 to fea_dim)
+                for (int k = 0; k < D; ++k) {
+                    float s = 0.0f;
+                    for (int f = 0; f < 6; ++f) {
+                        int fr = frames_processed + f;
+                        if (fr >= frames_need) fr = frames_need - 1;          // (the reference reads past its buffer here)
+                        s = f == 0 ? fea[(size_t)fr * D + k] : s + fea[(size_t)fr * D + k];
+                    }
+                    row[(size_t)ctx * D + k] = s / 6.0f;
+                }
+            }
+            int tf = frames_processed + j + cfg_.targ_offset;
+            if (tf >= frames_need) tf = frames_need - 1;
+            memcpy(targ + (size_t)sample_index[cur_sample] * OD, &tg[(size_t)tf * OD], sizeof(float) * OD);
+            ++cur_sample;
+        }
+        cur_frame_id = frames_before_sent_[cur_sent];
+        ++cur_sent;
+        frames_processed += seg;
+    }
+    return samples;
+}
+
+}  // namespace bp

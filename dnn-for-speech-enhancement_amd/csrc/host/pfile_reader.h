@@ -1,0 +1,54 @@
+// pfile_reader.h -- host-side producer of the trainer's inputs ("next" row N1 of SURVEY.md 8f):
+// ICSI Pfile pair (features + float targets) -> chunks of stacked, mean/variance-normalised input
+// frames + targets, exactly what the reference's Interface feeds to BP_GPU::train / CrossValid
+// (Interface.cc:468-1034, restated from its behaviour; formats in SURVEY.md Appendix B).
+//
+// Parity note: Interface.cc cannot be compiled in this image (it includes BP_GPU.h -> CUDA headers),
+// so this reader is pinned by an independent numpy restatement (tests/test_pfile_reader.py) and
+// not by reference-generated fixtures.
+#pragma once
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+namespace bp {
+
+struct ReaderConfig {
+    std::string fea_file, targ_file, norm_file;
+    int fea_dim = 0, fea_context = 1, targ_offset = 0, out_dim = 0;
+    int traincache = 0;          // samples per chunk
+    int input_dim = 0;           // layersizes[0]: fea_dim*ctx (plain) or fea_dim*(ctx+1) (NAT block appended)
+};
+
+class PfileReader {
+public:
+    explicit PfileReader(const ReaderConfig &cfg);
+    ~PfileReader();
+    // Interface::get_pfile_info (Interface.cc:468-555): headers, sentence tables, consistency checks
+    void open();
+    // Interface::get_chunk_info[_cv] (Interface.cc:558-686): plan chunks over sentences [st, en] (inclusive)
+    struct Plan { std::vector<int> chunk_frame_st; int sent_st = 0, sent_en = 0; unsigned total_samples = 0; };
+    Plan plan(int sent_st, int sent_en) const;
+    // Interface::Readchunk / Readchunk_cv (Interface.cc:689-1034): returns the number of samples; rows are
+    // written at a shuffled position when `shuffle` (train) else in order (CV).  in: [samples][input_dim],
+    // targ: [samples][out_dim].
+    int read_chunk(const Plan &p, int chunk_index, bool shuffle, float *in, float *targ);
+    unsigned total_frames() const { return total_frames_; }
+    unsigned total_sents() const { return total_sents_; }
+    const std::vector<int> &frames_before_sent() const { return frames_before_sent_; }
+    bool nat() const { return nat_; }
+    // Interface::GetRandIndex (Interface.cc:1044-1055): back-to-front Fisher-Yates on lrand48()
+    static void rand_index(int *vec, int len);
+
+private:
+    ReaderConfig cfg_;
+    FILE *fp_data_ = nullptr, *fp_targ_ = nullptr;
+    unsigned total_frames_ = 0, total_sents_ = 0;
+    std::vector<int> frames_before_sent_;
+    std::vector<float> mean_, dvar_;
+    bool nat_ = false;
+};
+
+[[noreturn]] void die(const char *fmt, ...);   // message + exit(0), the reference's error convention
+
+}  // namespace bp

@@ -1,0 +1,97 @@
+"""CPU tests of the "next"-row host code (csrc/host): Pfile reader / chunk planner / in-chunk shuffle and the
+weight-file format, against the independent restatement in tests/pfile_util.py (bit exact)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pfile_util as PU
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "dnn-for-speech-enhancement_amd", "csrc", "host")
+
+
+@pytest.fixture(scope="module")
+def dump_exe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("bin") / "reader_dump")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "cpp", "reader_dump.cc"),
+                           os.path.join(HOST, "pfile_reader.cpp"), os.path.join(HOST, "wts_io.cpp"), "-o", exe])
+    return exe
+
+
+CASES = [
+    # fea_dim, ctx, targ_offset, out_dim, traincache, nat, sentence lengths, sent range, seed
+    (5, 1, 0, 4, 7, False, [6, 9, 3, 12, 5], (0, 4), 11),
+    (6, 3, 1, 3, 8, True, [10, 2, 7, 15, 4, 9], (0, 5), 345),        # a sentence shorter than the context; cuts mid-sentence
+    (129, 11, 5, 129, 40, True, [60, 35, 80, 20], (1, 3), 7),         # the shipped geometry (129 bins, 11 frames, NAT, offset 5)
+    (4, 2, 0, 2, 1000, False, [5, 6, 7], (0, 2), 3),                  # everything in one chunk
+]
+
+
+@pytest.mark.parametrize("D,ctx,toff,OD,cache,nat,lens,rng_,seed", CASES)
+@pytest.mark.parametrize("shuffle", [0, 1])
+def test_reader_matches_restatement(tmp_path, dump_exe, D, ctx, toff, OD, cache, nat, lens, rng_, seed, shuffle):
+    rs = np.random.default_rng(seed)
+    n = sum(lens)
+    fea = rs.normal(size=(n, D)).astype(np.float32) * 3 + 1
+    tg = rs.normal(size=(n, OD)).astype(np.float32)
+    mean = rs.normal(size=D).astype(np.float32)
+    istd = (0.5 + rs.random(size=D)).astype(np.float32)
+    fp, tp, npth, out = (str(tmp_path / x) for x in ("f.pfile", "t.pfile", "n.norm", "o.bin"))
+    PU.write_pfile(fp, lens, fea); PU.write_pfile(tp, lens, tg); PU.write_norm(npth, mean, istd)
+    s0 = D * (ctx + 1) if nat else D * ctx
+    subprocess.check_call([dump_exe, "chunks", fp, tp, npth, str(D), str(ctx), str(toff), str(OD), str(cache), str(s0),
+                           str(rng_[0]), str(rng_[1]), str(shuffle), str(seed), out])
+    raw = np.fromfile(out, np.uint8)
+    nch, ts = np.frombuffer(raw, np.int32, 2, 0)
+    starts_c = np.frombuffer(raw, np.int32, nch, 8).tolist()
+    fb = np.cumsum(lens).tolist()
+    starts, total = PU.plan(fb, n, ctx, cache, rng_[0], rng_[1])
+    assert starts_c == starts and ts == total
+    # norm values as the C code sees them (text round trip)
+    mean_t = np.array([float("%.9g" % v) for v in mean], np.float32)
+    istd_t = np.array([float("%.9g" % v) for v in istd], np.float32)
+    sent_of = np.repeat(np.arange(len(lens)), lens)
+    r48 = PU.Rand48(seed)
+    o = 8 + 4 * nch
+    for ci in range(nch):
+        cnt = int(np.frombuffer(raw, np.int32, 1, o)[0]); o += 4
+        xin = np.frombuffer(raw, np.float32, cnt * s0, o).reshape(cnt, s0); o += 4 * cnt * s0
+        xtg = np.frombuffer(raw, np.float32, cnt * OD, o).reshape(cnt, OD); o += 4 * cnt * OD
+        n_exp = total - cache * ci if ci == nch - 1 else cache
+        assert cnt == max(n_exp, 0)
+        order = PU.rand_index(cnt, r48) if shuffle else list(range(cnt))
+        ein, etg = PU.read_chunk(fea, tg, sent_of, fb, mean_t, istd_t, starts, total, rng_[1], ci, ctx, cache, toff, nat, order)
+        assert np.array_equal(xin, ein), ("in", ci)
+        assert np.array_equal(xtg, etg), ("targ", ci)
+    assert o == raw.size
+
+
+def test_weight_file_bytes_and_roundtrip(tmp_path, dump_exe):
+    ls = [6, 4, 3]
+    rs = np.random.default_rng(1)
+    W = [None] + [rs.normal(size=(ls[l - 1], ls[l])).astype(np.float32) for l in (1, 2)]
+    b = [None] + [rs.normal(size=ls[l]).astype(np.float32) for l in (1, 2)]
+    a, c = str(tmp_path / "a.wts"), str(tmp_path / "c.wts")
+    PU.write_wts(a, ls, W, b)
+    subprocess.check_call([dump_exe, "wts", a, c, "3", "6", "4", "3"])
+    assert open(a, "rb").read() == open(c, "rb").read()                 # byte-identical re-write
+    raw = open(c, "rb").read()
+    assert raw[:20] == np.array([10, 4, 6, 0, 10], "<i4").tobytes() and raw[20:30] == b"weights12\0"
+    W2, b2 = PU.read_wts(c, ls)
+    assert all(np.array_equal(W2[l], W[l]) and np.array_equal(b2[l], b[l]) for l in (1, 2))
+    # size mismatch is reported with the reference's message
+    r = subprocess.run([dump_exe, "wts", a, c, "3", "6", "5", "3"], capture_output=True, text=True)
+    assert r.returncode == 3 and "init weights node nums do not match" in r.stdout
+
+
+def test_rand48_matches_libc():
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.lrand48.restype = ctypes.c_long
+    libc.drand48.restype = ctypes.c_double
+    libc.srand48(ctypes.c_long(1234))
+    r = PU.Rand48(1234)
+    assert [libc.lrand48() for _ in range(5)] == [r.lrand48() for _ in range(5)]
+    assert [libc.drand48() for _ in range(3)] == [r.drand48() for _ in range(3)]
