@@ -177,7 +177,7 @@ def main():
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-            for k, v in pm.items():
+            for k, v in pm.get("kernels", pm).items():
                 if "bp_gemm<32, 64, 64, 1, 2, true, false, 0" in k:
                     traffic = (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6
         except Exception:
