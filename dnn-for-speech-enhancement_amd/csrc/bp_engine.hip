@@ -36,7 +36,6 @@ struct bp_handle {
     int B, Bg;                   // local / global bunch
     int cap, chunk_frames;
     hipStream_t own_stream, stream;
-    bool dual;                   // paired backward launches (bp_gemm_dual)
     bool grouped;                // all wide wgrad+update problems of a step in one grouped launch
     float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
@@ -129,7 +128,6 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
     h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
     h->grouped = getenv("BP_NO_GROUPED") == nullptr;
-    h->dual = getenv("BP_DUAL") != nullptr;     // measured 1.5 % slower than back-to-back launches: opt-in
     h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
     h->last_ms = 0.f; h->last_bunches = 0;
 
@@ -257,17 +255,19 @@ static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const f
 }
 
 // A prepared backward GEMM: arguments + which tile configuration it uses.
-enum { CFG_DGRAD_WIDE, CFG_DGRAD_NARROW, CFG_WGRAD_WIDE, CFG_WGRAD_NARROW };
+enum { CFG_DGRAD_WIDE, CFG_DGRAD_NARROW, CFG_WGRAD };
 struct Prepared { GemmArgs g; EpiArgs e; int M, N, cfg; bool fused; };
 
 using KDgradWide = GemmKernel<32, 64, 64, 1, 2, true, true, EPI_DGRAD>;
 using KDgradNarrow = GemmKernel<32, 32, 64, 1, 1, true, true, EPI_DGRAD>;
-// wgrad 128x64 tiles: 25 % less operand traffic through L2 than 64x64 (measured 30.0 vs 33.8 us on
-// the 2048x2048 layer); a narrow output layer keeps 64x64 so that more workgroups exist
-template <int EPI, int NT_S = 0> using KWgradWide = GemmKernel<128, 64, 16, 2, 2, false, false, EPI, 1, NT_S>;
-// bunch of 256 frames = 16 k-tiles: fully unrolled k-loop with the W/delta fetch spread over it
-using KWgradWide256 = KWgradWide<EPI_WGRAD_UPDATE, 16>;
-template <int EPI> using KWgradNarrow = GemmKernel<64, 64, 32, 2, 2, false, false, EPI>;
+// wgrad: 64x64x32 tiles, 4 waves of one 32x32 block each.  168 VGPRs => 3 workgroups per CU, which is what
+// lets the prologue / W,delta round trip of one workgroup hide behind the MFMA phase of the others
+// (128x64 tiles move 25 % less through L2 but fit only 2 per CU: 0.242 vs 0.230 ms per C2 step).
+template <int EPI> using KWgrad = GemmKernel<64, 64, 32, 2, 2, false, false, EPI>;
+// bunch of 256 frames = 8 k-tiles: fully unrolled k-loop with the W/delta fetch spread over it
+using KWgrad256 = GemmKernel<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE, 1, 8>;
+// data-parallel gradient store (no W/delta to carry): 128x64x16 tiles are 136 VGPRs and measured faster there
+using KWgradStore = GemmKernel<128, 64, 16, 2, 2, false, false, EPI_WGRAD_STORE>;
 
 // dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T)     (BP_GPU.cu:611-637)
 static Prepared prep_dgrad(bp_handle *h, int l, int M)
@@ -301,74 +301,18 @@ static Prepared prep_wgrad(bp_handle *h, int l, int M, const float *y_prev, bool
         p.e.C = h->grad + h->g_off[l];
         p.e.bias_g = h->grad + h->g_off[l] + (size_t)prev * cur;
     }
-    p.M = prev; p.N = cur; p.cfg = cur > 512 ? CFG_WGRAD_WIDE : CFG_WGRAD_NARROW; p.fused = fused;
+    p.M = prev; p.N = cur; p.cfg = CFG_WGRAD; p.fused = fused;
     return p;
 }
 
-template <class K>
-static hipError_t run_one(hipStream_t st, Prepared &p, int bm, int bn)
-{
-    p.g.tiles_m = (p.M + bm - 1) / bm; p.g.tiles_n = (p.N + bn - 1) / bn;
-    hipLaunchKernelGGL((bp_gemm_dual<K, K>), dim3(p.g.tiles_m * p.g.tiles_n), dim3(256), 0, st, p.g, p.e, p.g, p.e,
-                       p.g.tiles_m * p.g.tiles_n);
-    return hipGetLastError();
-}
-static hipError_t run_single(hipStream_t st, Prepared p)
-{
-    switch (p.cfg) {
-    case CFG_DGRAD_WIDE: return run_one<KDgradWide>(st, p, 32, 64);
-    case CFG_DGRAD_NARROW: return run_one<KDgradNarrow>(st, p, 32, 32);
-    case CFG_WGRAD_WIDE:
-        if (p.fused && p.g.K == 256) return run_one<KWgradWide256>(st, p, 128, 64);
-        return p.fused ? run_one<KWgradWide<EPI_WGRAD_UPDATE>>(st, p, 128, 64)
-                       : run_one<KWgradWide<EPI_WGRAD_STORE>>(st, p, 128, 64);
-    default: return p.fused ? run_one<KWgradNarrow<EPI_WGRAD_UPDATE>>(st, p, 64, 64)
-                            : run_one<KWgradNarrow<EPI_WGRAD_STORE>>(st, p, 64, 64);
-    }
-}
-
-template <class KA, class KB>
-static hipError_t run_two(hipStream_t st, Prepared &a, int am, int an, Prepared &b, int bm, int bn)
-{
-    a.g.tiles_m = (a.M + am - 1) / am; a.g.tiles_n = (a.N + an - 1) / an;
-    b.g.tiles_m = (b.M + bm - 1) / bm; b.g.tiles_n = (b.N + bn - 1) / bn;
-    const int nA = a.g.tiles_m * a.g.tiles_n, nB = b.g.tiles_m * b.g.tiles_n;
-    hipLaunchKernelGGL((bp_gemm_dual<KA, KB>), dim3(nA + nB), dim3(256), 0, st, a.g, a.e, b.g, b.e, nA);
-    return hipGetLastError();
-}
-// Two independent problems in one launch when a fused instantiation exists for the pair, else
-// back to back.  A is dispatched first (the long MFMA-heavy one), B fills in beside it.
-static hipError_t run_pair(hipStream_t st, Prepared a, Prepared b, bool allow_dual)
-{
-    if (allow_dual && b.cfg >= CFG_WGRAD_WIDE) {
-        const bool fu = b.fused;
-        if (a.cfg == CFG_DGRAD_WIDE && b.cfg == CFG_WGRAD_WIDE)
-            return fu ? run_two<KDgradWide, KWgradWide<EPI_WGRAD_UPDATE>>(st, a, 32, 64, b, 128, 64)
-                      : run_two<KDgradWide, KWgradWide<EPI_WGRAD_STORE>>(st, a, 32, 64, b, 128, 64);
-        if (a.cfg == CFG_DGRAD_WIDE && b.cfg == CFG_WGRAD_NARROW)
-            return fu ? run_two<KDgradWide, KWgradNarrow<EPI_WGRAD_UPDATE>>(st, a, 32, 64, b, 64, 64)
-                      : run_two<KDgradWide, KWgradNarrow<EPI_WGRAD_STORE>>(st, a, 32, 64, b, 64, 64);
-        if (a.cfg == CFG_WGRAD_WIDE && b.cfg == CFG_WGRAD_WIDE && a.fused == fu)
-            return fu ? run_two<KWgradWide<EPI_WGRAD_UPDATE>, KWgradWide<EPI_WGRAD_UPDATE>>(st, a, 128, 64, b, 128, 64)
-                      : run_two<KWgradWide<EPI_WGRAD_STORE>, KWgradWide<EPI_WGRAD_STORE>>(st, a, 128, 64, b, 128, 64);
-        if (a.cfg == CFG_WGRAD_NARROW && b.cfg == CFG_WGRAD_NARROW && a.fused == fu)
-            return fu ? run_two<KWgradNarrow<EPI_WGRAD_UPDATE>, KWgradNarrow<EPI_WGRAD_UPDATE>>(st, a, 64, 64, b, 64, 64)
-                      : run_two<KWgradNarrow<EPI_WGRAD_STORE>, KWgradNarrow<EPI_WGRAD_STORE>>(st, a, 64, 64, b, 64, 64);
-    }
-    hipError_t er = run_single(st, a);
-    if (er != hipSuccess) return er;
-    return run_single(st, b);
-}
-
-// Several wgrad problems in one grouped launch when they all use the wide configuration, else one
-// launch each.
-template <class K>
-static hipError_t run_multi_wide(hipStream_t st, Prepared *ps, int n)
+// n (1..4) independent problems of one tile configuration in one launch (bp_gemm_multi).
+template <class K, int BMT, int BNT>
+static hipError_t run_multi(hipStream_t st, Prepared *ps, int n)
 {
     MultiArgs a; memset(&a, 0, sizeof(a));
     int t = 0;
     for (int i = 0; i < n; ++i) {
-        ps[i].g.tiles_m = (ps[i].M + 127) / 128; ps[i].g.tiles_n = (ps[i].N + 63) / 64;
+        ps[i].g.tiles_m = (ps[i].M + BMT - 1) / BMT; ps[i].g.tiles_n = (ps[i].N + BNT - 1) / BNT;
         a.g[i] = ps[i].g; a.e[i] = ps[i].e; a.first_tile[i] = t;
         t += ps[i].g.tiles_m * ps[i].g.tiles_n;
     }
@@ -376,25 +320,33 @@ static hipError_t run_multi_wide(hipStream_t st, Prepared *ps, int n)
     hipLaunchKernelGGL((bp_gemm_multi<K>), dim3(t), dim3(256), 0, st, a);
     return hipGetLastError();
 }
+
+// The wgrad problems ps[0..n) (all fused or all store): grouped launches of up to 4 problems, or one each.
 static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
 {
-    bool wide = grouped && n >= 2 && n <= 4;
-    for (int i = 0; i < n; ++i) wide = wide && ps[i].cfg == CFG_WGRAD_WIDE && ps[i].fused == ps[0].fused;
-    if (wide) {
-        bool k256 = ps[0].fused;
-        for (int i = 0; i < n; ++i) k256 = k256 && ps[i].g.K == 256;
-        if (k256) return run_multi_wide<KWgradWide256>(st, ps, n);
-        return ps[0].fused ? run_multi_wide<KWgradWide<EPI_WGRAD_UPDATE>>(st, ps, n)
-                           : run_multi_wide<KWgradWide<EPI_WGRAD_STORE>>(st, ps, n);
+    for (int i = 0; i < n;) {
+        const int m = grouped ? (n - i < 4 ? n - i : 4) : 1;
+        bool k256 = ps[i].fused;
+        for (int j = 0; j < m; ++j) k256 = k256 && ps[i + j].g.K == 256;
+        hipError_t er;
+        if (k256) er = run_multi<KWgrad256, 64, 64>(st, ps + i, m);
+        else if (ps[i].fused) er = run_multi<KWgrad<EPI_WGRAD_UPDATE>, 64, 64>(st, ps + i, m);
+        else er = run_multi<KWgradStore, 128, 64>(st, ps + i, m);
+        if (er != hipSuccess) return er;
+        i += m;
     }
-    for (int i = 0; i < n; ++i) { hipError_t er = run_single(st, ps[i]); if (er != hipSuccess) return er; }
     return hipSuccess;
 }
 
-static hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M) { return run_single(st, prep_dgrad(h, l, M)); }
+static hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M)
+{
+    Prepared p = prep_dgrad(h, l, M);
+    return p.cfg == CFG_DGRAD_WIDE ? run_multi<KDgradWide, 32, 64>(st, &p, 1) : run_multi<KDgradNarrow, 32, 32>(st, &p, 1);
+}
 static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, bool fused)
 {
-    return run_single(st, prep_wgrad(h, l, M, y_prev, fused));
+    Prepared p = prep_wgrad(h, l, M, y_prev, fused);
+    return run_wgrads(st, &p, 1, false);
 }
 
 static hipError_t mask_range(bp_handle *h, int first, int n)
@@ -428,32 +380,17 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
     const float *tg = h->targ + (size_t)first * h->ld[L - 1];
     for (int l = 1; l < L; ++l)
         CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
-    if (h->dual && L > 2) {
-        // optional paired launches (bp_gemm_dual): dgrad(L-1); {dgrad(l-1) || wgrad(l)} for l = L-1..3;
-        // {wgrad(2) || wgrad(1)}.  wgrad(l) never shares a launch with dgrad(l), which reads W_l.
-        CKE(launch_dgrad(h, h->stream, L - 1, B));
-        for (int l = L - 1; l >= 3; --l)
-            CKE(run_pair(h->stream, prep_dgrad(h, l - 1, B), prep_wgrad(h, l, B, h->y[l - 1], fused), true));
-        CKE(run_pair(h->stream, prep_wgrad(h, 2, B, h->y[1], fused), prep_wgrad(h, 1, B, x0, fused), true));
-    } else if (h->grouped) {
-        // Every dgrad of the step reads pre-update weights (BP_GPU.cu:636 runs before :643-652 of the
-        // same layer and the lower layers' updates come later), so the wgrad+update problems can all
-        // wait until the last dgrad and then share ONE grouped launch (bp_gemm_multi), largest first.
-        // A narrow layer (output layer) keeps its own small launch right after its dgrad.
-        Prepared ws[BP_MAXLAYER]; int nw = 0;
-        for (int l = L - 1; l >= 1; --l) {
-            if (l != 1) CKE(launch_dgrad(h, h->stream, l, B));
-            Prepared p = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
-            if (p.cfg == CFG_WGRAD_WIDE && nw < 4) ws[nw++] = p; else CKE(run_single(h->stream, p));
-        }
-        for (int i = 0; i < nw / 2; ++i) { Prepared t = ws[i]; ws[i] = ws[nw - 1 - i]; ws[nw - 1 - i] = t; }  // layer 1 first
-        if (nw) CKE(run_wgrads(h->stream, ws, nw, true));
-    } else {
-        for (int l = L - 1; l >= 1; --l) {
-            if (l != 1) CKE(launch_dgrad(h, h->stream, l, B));
-            CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], fused));
-        }
+    // Every dgrad of the step reads pre-update weights (BP_GPU.cu:636 runs before :643-652 of the same
+    // layer and the lower layers' updates come later), so the wgrad+update problems can all wait until
+    // the last dgrad and share grouped launches (bp_gemm_multi), layer 1 (the largest) first.
+    Prepared ws[BP_MAXLAYER]; int nw = 0;
+    for (int l = L - 1; l >= 1; --l) {
+        if (l != 1) CKE(launch_dgrad(h, h->stream, l, B));
+        if (h->grouped) ws[nw++] = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
+        else CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], fused));
     }
+    for (int i = 0; i < nw / 2; ++i) { Prepared t = ws[i]; ws[i] = ws[nw - 1 - i]; ws[nw - 1 - i] = t; }
+    if (nw) CKE(run_wgrads(h->stream, ws, nw, true));
 #undef CKE
     return hipSuccess;
 }

@@ -756,19 +756,6 @@ __global__ __launch_bounds__(256, 2) void bp_gemm_multi(const MultiArgs a)
     K::run(a.g[p], a.e[p], b - a.first_tile[p], a.first_tile[p + 1] - a.first_tile[p], 0, smem);
 }
 
-// Two INDEPENDENT problems in one launch: workgroups [0, nA) run problem A, the rest problem B
-// (e.g. the backward pair {dgrad(l-1), wgrad+update(l)}, which both only need dEdX_l).  Opt-in:
-// on MI355X it measured 1.5 % slower than the two launches back to back.
-template <class KA, class KB>
-__global__ __launch_bounds__(256, 2) void bp_gemm_dual(const GemmArgs gA, const EpiArgs eA, const GemmArgs gB,
-                                                    const EpiArgs eB, int nA)
-{
-    constexpr int SM = KA::SMEM > KB::SMEM ? KA::SMEM : KB::SMEM;
-    __shared__ __attribute__((aligned(16))) float smem[SM];
-    if ((int)blockIdx.x < nA) KA::run(gA, eA, blockIdx.x, nA, 0, smem);
-    else KB::run(gB, eB, (int)blockIdx.x - nA, (int)gridDim.x - nA, 0, smem);
-}
-
 // ------------------------------------------------------------------ small kernels
 // Visible-layer dropout of the resident chunk (BP_GPU.cu:536-539 masks the device copy of the
 // chunk in place; here the masked frames go to a second buffer so the chunk stays reusable).
