@@ -727,7 +727,7 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
 };   // GemmKernel
 
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0>
-__global__ __launch_bounds__(256, 2) void bp_gemm(const GemmArgs g, const EpiArgs e)
+__global__ __launch_bounds__(256, ((BM + BN) * BK > 96 * 64) ? 1 : 2) void bp_gemm(const GemmArgs g, const EpiArgs e)
 {
     using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>;
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
@@ -747,7 +747,7 @@ struct MultiArgs {
     int n;
 };
 template <class K>
-__global__ __launch_bounds__(256, 2) void bp_gemm_multi(const MultiArgs a)
+__global__ __launch_bounds__(256, (K::SMEM * 4 > 80 * 1024) ? 1 : 2) void bp_gemm_multi(const MultiArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     const int b = blockIdx.x;

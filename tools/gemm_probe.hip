@@ -80,11 +80,11 @@ int main(int argc, char **argv)
 #define FWD(BM, BN, BK, WM, WN, PF) vs.push_back({"fwd  " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); go<BM, BN, BK, WM, WN, true, false, EPI_FWD_HIDDEN, PF>(s, g, e, B, H, 0); }, fl})
 #define DGR(BM, BN, BK, WM, WN, PF) vs.push_back({"dgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); go<BM, BN, BK, WM, WN, true, true, EPI_DGRAD, PF>(s, g, e, B, H, 0); }, fl})
 #define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " grid" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, 2.0 * H * H * (double)KW})
-    FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);
+    FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 128, 1, 2, 1); FWD(64, 32, 128, 2, 1, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);
     FWD(64, 32, 64, 2, 1, 1); FWD(64, 32, 64, 2, 1, 2);
     FWD(32, 32, 64, 1, 1, 1); FWD(32, 32, 64, 1, 1, 2); FWD(32, 32, 128, 1, 1, 1);
     FWD(64, 64, 32, 2, 2, 1);
-    DGR(32, 64, 64, 1, 2, 1); DGR(32, 64, 64, 1, 2, 2); DGR(64, 32, 64, 2, 1, 1); DGR(32, 32, 64, 1, 1, 1); DGR(32, 32, 64, 1, 1, 2);
+    DGR(32, 64, 64, 1, 2, 1); DGR(32, 64, 128, 1, 2, 1); DGR(32, 64, 64, 1, 2, 2); DGR(64, 32, 64, 2, 1, 1); DGR(32, 32, 64, 1, 1, 1); DGR(32, 32, 64, 1, 1, 2);
     WGR(64, 64, 32, 2, 2, 1, 0); WGR(64, 64, 32, 2, 2, 1, 512); WGR(64, 64, 32, 2, 2, 1, 256); WGR(64, 64, 32, 2, 2, 1, 768);
     WGR(128, 64, 16, 2, 2, 1, 0); WGR(128, 64, 16, 2, 2, 1, 256); WGR(128, 64, 32, 2, 2, 1, 256);
     WGR(64, 128, 16, 2, 2, 1, 0); WGR(64, 128, 16, 2, 2, 1, 256);
