@@ -178,7 +178,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
             for k, v in pm.get("kernels", pm).items():
-                if "bp_gemm<32, 64, 64, 1, 2, true, false, 0" in k:
+                if "bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>" in k:      # hidden-layer forward (TAG 0)
                     traffic = (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6
         except Exception:
             traffic = None

@@ -196,14 +196,14 @@ extern "C" int bp_sync(bp_handle *h)
 }
 
 // ------------------------------------------------------------------ launches
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int TAG = 0>
 static hipError_t launch(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N, int max_grid = 0)
 {
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     int grid = g.tiles_m * g.tiles_n;
     if (max_grid > 0 && grid > max_grid) grid = max_grid;     // persistent: workgroups loop over tiles
-    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>), dim3(grid), dim3(256), 0, st, g, e);
+    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, 0, TAG>), dim3(grid), dim3(256), 0, st, g, e);
     return hipGetLastError();
 }
 
@@ -231,6 +231,7 @@ static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const f
         e.seed_lo = (uint32_t)h->cfg.seed; e.seed_hi = (uint32_t)(h->cfg.seed >> 32);
         e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
         if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
+        if (l == 1) return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1, 1>(st, g, e, M, cur);   // (own name in profiles)
         return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
     }
     e.scale = 2.0f / (float)h->Bg;                       // kernSubClean: 2.0f/rows (global rows under DP)
@@ -329,7 +330,8 @@ static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
 {
     for (int i = 0; i < n;) {
         const int m = grouped ? (n - i < 4 ? n - i : 4) : 1;
-        bool k256 = ps[i].fused;
+        static const bool no_static = getenv("BP_WGRAD_DYNAMIC") != nullptr;    // development A/B switch
+        bool k256 = ps[i].fused && !no_static;
         for (int j = 0; j < m; ++j) k256 = k256 && ps[i + j].g.K == 256;
         hipError_t er;
         if (k256) er = run_multi<KWgrad256, 64, 64>(st, ps + i, m);

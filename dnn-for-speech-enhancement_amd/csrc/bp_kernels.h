@@ -103,11 +103,63 @@ __device__ __forceinline__ float act_bwd(int act, float y)
 // it: bias (fwd), targ (fwd_out) / y_prev (dgrad) / W (wgrad) in p0, delta_W (wgrad) in p1.
 struct EpiPre { float bias; f32x16 p0, p1; };
 
+// A pointer the compiler cannot prove wave-uniform, forced into SGPRs (so that loads/stores through it
+// take the  saddr + 32-bit lane offset  form and need no per-row 64-bit address VGPRs).
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    typedef __attribute__((address_space(1))) T *GlobalPtr;      // keep it a GLOBAL pointer (not flat)
+    return (T *)(GlobalPtr)(((unsigned long long)hi << 32) | lo);
+}
+
+// Pin a wave-uniform pointer in an SGPR pair and hide its derivation from the optimiser, so that
+// `*(T*)((char*)sgpr_row_base(p) + lane_byte_offset)` is selected as  global_load v, v_off, s[base]
+// instead of being reassociated into per-lane 64-bit addresses.
+template <class T>
+__device__ __forceinline__ T *sgpr_row_base(T *p)
+{
+    typedef __attribute__((address_space(1))) T *GlobalPtr;
+    GlobalPtr q = (GlobalPtr)p;
+    asm volatile("" : "+s"(q));
+    return (T *)q;
+}
+
+// wgrad block orientation.  1: the natural MFMA layout (lane -> column n, registers -> rows): every
+// W / delta load and store is two full 128-byte rows.  0: transposed block (operands swapped in the
+// MFMA), lane -> row m and 4 registers -> 4 consecutive columns: float4 accesses, but each
+// instruction touches 32 rows x 32 bytes (quarter lines).
+#ifndef BP_WGRAD_LANE_N
+#define BP_WGRAD_LANE_N 1
+#endif
+
 // Registers [R0, R0+RN) of one 32x32 accumulator block (after an in-workgroup k-split every wave
 // finishes 16/KS of the block's registers).
 template <int EPI, int R0, int RN>
 __device__ __forceinline__ void epilogue_fetch(const EpiArgs &e, int mb, int nb, int lane, EpiPre &p)
 {
+    if constexpr (EPI == EPI_WGRAD_UPDATE && BP_WGRAD_LANE_N) {
+        // uniform row base (SGPRs) + one per-lane 32-bit offset: no per-row address VGPRs.  m_limit is a
+        // multiple of 32 (padded widths), so a 32-row block is wholly inside or wholly outside the matrix;
+        // outside blocks read row 0 and are never stored.
+        const int mbc = mb < e.m_limit ? mb : 0;
+        const float *cw = uniform_ptr(e.C + (size_t)mbc * e.ldc + nb);
+        const float *cd = uniform_ptr(e.aux2 + (size_t)mbc * e.ldc + nb);
+        const unsigned ldc = __builtin_amdgcn_readfirstlane(e.ldc);
+        const unsigned lob = 4u * ((unsigned)(4 * (lane >> 5)) * (unsigned)e.ldc + (unsigned)(lane & 31));   // bytes
+#pragma unroll
+        for (int r = R0; r < R0 + RN; ++r) {
+            const unsigned ro = (unsigned)((r & 3) + 8 * (r >> 2)) * ldc;
+#if defined(BP_ABLATE) && (BP_ABLATE & 16)
+            p.p0[r] = 0.f; p.p1[r] = 0.f; (void)cw; (void)cd; (void)ro; (void)lob;
+#else
+            p.p0[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sgpr_row_base(cw + ro)) + lob);
+            p.p1[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sgpr_row_base(cd + ro)) + lob);
+#endif
+        }
+        return;
+    }
     if constexpr (EPI == EPI_WGRAD_UPDATE) {
         // transposed block (GemmCfg::SWAP): lane -> row m, registers 4q..4q+3 -> columns n0..n0+3
         const int m = mb + (lane & 31);
@@ -145,6 +197,31 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
                                                const EpiPre &p)
 {
     static_assert(RN % 4 == 0 && R0 % 4 == 0, "register range must cover whole 4-row groups");
+    if constexpr ((EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) && BP_WGRAD_LANE_N) {
+        const int n = nb + (lane & 31);
+        if (n >= e.n_limit || mb >= e.m_limit) return;              // (m_limit % 32 == 0: whole block in or out)
+        float *cw = uniform_ptr(e.C + (size_t)mb * e.ldc + nb);
+        const unsigned ldc = __builtin_amdgcn_readfirstlane(e.ldc);
+        const unsigned lob = 4u * ((unsigned)(4 * (lane >> 5)) * (unsigned)e.ldc + (unsigned)(lane & 31));   // bytes
+#pragma unroll
+        for (int r = R0; r < R0 + RN; ++r) {
+            const unsigned ro = (unsigned)((r & 3) + 8 * (r >> 2)) * ldc;
+            if constexpr (EPI == EPI_WGRAD_UPDATE) {
+                float *cd = uniform_ptr(e.aux2 + (size_t)mb * e.ldc + nb);
+                const float w = p.p0[r];
+                const float d = e.mom * p.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);   // kernUpdatedelta
+#if defined(BP_ABLATE) && (BP_ABLATE & 8)
+                if (d == 1.2345e-30f) cw[lob] = d;
+#else
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cd + ro)) + lob) = d;
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cw + ro)) + lob) = d + 1.0f * w;   // kernAccSum
+#endif
+            } else {
+                *reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cw + ro)) + lob) = acc[r];
+            }
+        }
+        return;
+    }
     if constexpr (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) {
         // transposed block (GemmCfg::SWAP): lane -> row m, registers 4q..4q+3 -> columns n0..n0+3
         const int m = mb + (lane & 31);
@@ -288,7 +365,7 @@ struct GemmCfg {
     // one row m of W/delta/G and, in registers 4q..4q+3, four CONSECUTIVE columns -- so the epilogue
     // reads and writes W, delta, G as float4 (4x fewer memory instructions than one dword per
     // register; the update's loads/stores are instruction-issue bound, not bandwidth bound).
-    static constexpr bool SWAP = BIASG;
+    static constexpr bool SWAP = BIASG && !BP_WGRAD_LANE_N;
     static_assert(WM * WN * KS == 4 && TM >= 1 && TN >= 1, "wave layout");
     static_assert(BK % (2 * KS) == 0 && BK % 4 == 0, "BK");
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
@@ -334,11 +411,19 @@ struct GemmCfg {
     }
     static __device__ __forceinline__ void load_a(Regs &r, int i, const float *pa, const Offs &o)
     {
+#if defined(BP_ABLATE) && (BP_ABLATE & 1)     // timing experiments only: no global operand loads
+        r.a[i] = make_float4((float)o.a[i], 0.f, 0.f, 0.f); (void)pa;
+#else
         r.a[i] = *reinterpret_cast<const float4 *>(pa + o.a[i]);
+#endif
     }
     static __device__ __forceinline__ void load_b(Regs &r, int i, const float *pb, const Offs &o)
     {
+#if defined(BP_ABLATE) && (BP_ABLATE & 1)
+        r.b[i] = make_float4((float)o.b[i], 0.f, 0.f, 0.f); (void)pb;
+#else
         r.b[i] = *reinterpret_cast<const float4 *>(pb + o.b[i]);
+#endif
     }
     static __device__ __forceinline__ void load(Regs &r, const float *pa, const float *pb, const Offs &o)
     {
@@ -353,6 +438,10 @@ struct GemmCfg {
     {
         const int f = tid + i * 256;
         const float4 v = r.a[i];          // (a local copy keeps the register set out of scratch)
+#if defined(BP_ABLATE) && (BP_ABLATE & 2)     // timing experiments only: no LDS staging stores
+        if (v.x == 1.2345e-30f) As[f] = v.y;
+        return;
+#endif
         if constexpr (A_KC) {
             const int l8 = f % LPS, seg = f / LPS, row = seg % BM, k4 = (seg / BM) * LPS + l8;
             As[(k4 * 4 + 0) * LDA_S + row] = v.x; As[(k4 * 4 + 1) * LDA_S + row] = v.y;
@@ -366,6 +455,10 @@ struct GemmCfg {
     {
         const int f = tid + i * 256;
         const float4 v = r.b[i];
+#if defined(BP_ABLATE) && (BP_ABLATE & 2)
+        if (v.x == 1.2345e-30f) Bs[f] = v.y;
+        return;
+#endif
         if constexpr (B_KC) {
             const int l8 = f % LPS, seg = f / LPS, row = seg % BN, k4 = (seg / BN) * LPS + l8;
             Bs[(k4 * 4 + 0) * LDB_S + row] = v.x; Bs[(k4 * 4 + 1) * LDB_S + row] = v.y;
@@ -473,12 +566,14 @@ struct GemmKernel {
     static constexpr int BIASRED = BIASG ? 256 / (BN / 4) * BN : 0;
     static constexpr int SMEM0 = (2 * STAGE > RED) ? 2 * STAGE : RED;
     static constexpr int SMEM = SMEM0 > BIASRED ? SMEM0 : BIASRED;       // floats of LDS
+    // workgroups per CU the register allocator must leave room for (launch bounds)
+    static constexpr int MIN_WG = (SMEM * 4 > 80 * 1024) ? 1 : (STATIC_K ? 3 : 2);
 
 static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &e_in, int first_block, int stride,
                                            int block_y, float *smem)
 {
     using Regs = typename Cfg::Regs;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform => SGPR row bases
     const int ks = wave / (WM * WN), wq = wave % (WM * WN), wm = wq / WN, wn = wq % WN;
     GemmArgs g = g_in;
     EpiArgs e = e_in;
@@ -596,6 +691,7 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
                                                                      r1, PA((T) + 2), PB((T) + 2), offs, tid, bsum);    \
             __syncthreads();                                                                                   \
             epilogue_fetch_pieces<EPI, TM, TN, (T) * PER, ((T) + 1) * PER>(e, mb0, nb0, lane, pre);            \
+            if constexpr ((T) < 4) TRACE(4 + (T));                                                             \
         }
         SBODY(0) SBODY(1) SBODY(2) SBODY(3) SBODY(4) SBODY(5) SBODY(6) SBODY(7)
         SBODY(8) SBODY(9) SBODY(10) SBODY(11) SBODY(12) SBODY(13) SBODY(14) SBODY(15)
@@ -726,8 +822,9 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
 }
 };   // GemmKernel
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0>
-__global__ __launch_bounds__(256, ((BM + BN) * BK > 96 * 64) ? 1 : 2) void bp_gemm(const GemmArgs g, const EpiArgs e)
+// TAG only separates instantiations by name (profilers report per kernel name): 1 = input-layer forward.
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0, int TAG = 0>
+__global__ __launch_bounds__(256, (GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>::MIN_WG)) void bp_gemm(const GemmArgs g, const EpiArgs e)
 {
     using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>;
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
@@ -747,7 +844,7 @@ struct MultiArgs {
     int n;
 };
 template <class K>
-__global__ __launch_bounds__(256, (K::SMEM * 4 > 80 * 1024) ? 1 : 2) void bp_gemm_multi(const MultiArgs a)
+__global__ __launch_bounds__(256, K::MIN_WG) void bp_gemm_multi(const MultiArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     const int b = blockIdx.x;

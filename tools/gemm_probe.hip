@@ -80,6 +80,8 @@ int main(int argc, char **argv)
 #define FWD(BM, BN, BK, WM, WN, PF) vs.push_back({"fwd  " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); go<BM, BN, BK, WM, WN, true, false, EPI_FWD_HIDDEN, PF>(s, g, e, B, H, 0); }, fl})
 #define DGR(BM, BN, BK, WM, WN, PF) vs.push_back({"dgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); go<BM, BN, BK, WM, WN, true, true, EPI_DGRAD, PF>(s, g, e, B, H, 0); }, fl})
 #define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " grid" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, 2.0 * H * H * (double)KW})
+    // same kernel, every k-row of W aliased to row 0 (ldb = 0): operands always hit L2 -> isolates HBM/MALL latency
+    vs.push_back({"fwdL2 32x64x64 w1x2 pf1 (ldb=0)", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.ldb = 0; go<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>(s, g, e, B, H, 0); }, fl});
     FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 128, 1, 2, 1); FWD(64, 32, 128, 2, 1, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);
     FWD(64, 32, 64, 2, 1, 1); FWD(64, 32, 64, 2, 1, 2);
     FWD(32, 32, 64, 1, 1, 1); FWD(32, 32, 64, 1, 1, 2); FWD(32, 32, 128, 1, 1, 1);
@@ -96,15 +98,21 @@ int main(int argc, char **argv)
     vs.push_back({"mfma peak: 4 chains/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<4>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0 * 4});
 
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    const int lds[] = {2048};
-    for (int li = 0; li < 1; ++li) {
+    const int lds[] = {2048, 2112, 2176, 2304};
+    const int nld = getenv("PROBE_LDS") ? 4 : 1;
+    for (int li = 0; li < nld; ++li) {
     LD = lds[li];
     printf("==== leading dimension %d floats\n", LD);
     const int rounds = 5, iters = 20;
     std::vector<std::vector<float>> t(vs.size());
     for (int r = 0; r < rounds; ++r)
         for (size_t v = 0; v < vs.size(); ++v) {
-            if (filter[0] && vs[v].name.find(filter) == std::string::npos) continue;
+            if (filter[0]) {      // comma-separated substrings, any match
+                bool hit = false; std::string f(filter); size_t p0 = 0;
+                while (p0 <= f.size()) { size_t p1 = f.find(',', p0); if (p1 == std::string::npos) p1 = f.size();
+                    if (p1 > p0 && vs[v].name.find(f.substr(p0, p1 - p0)) != std::string::npos) hit = true; p0 = p1 + 1; }
+                if (!hit) continue;
+            }
             vs[v].run(st); vs[v].run(st);
             CK(hipEventRecord(a, st));
             for (int i = 0; i < iters; ++i) vs[v].run(st);

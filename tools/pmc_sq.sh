@@ -1,0 +1,9 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_sq; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_F32 SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM" "MfmaUtil"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $O/p$i -o p -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/p$i.err
+done
+python $R/tools/pmc_any.py $O/sq.json $O/p1 $O/p2 $O/p3 $O/p4 > $O/sq.txt
+find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
