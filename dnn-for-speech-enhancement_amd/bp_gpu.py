@@ -33,11 +33,21 @@ ABI_SYMBOLS = [
     "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident", "bp_grad_buffer",
     "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_dp_forward_layer", "bp_dp_dgrads", "bp_dp_wgrad_layer", "bp_apply_update_layer", "bp_advance_step",
     "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
+    "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
 ]
 
 
 class BPError(RuntimeError):
     pass
+
+
+class BPWindowChunk(C.Structure):
+    """bp_window_chunk (include/bp_c_api.h): raw frames + index tables, stacked on the device."""
+    _fields_ = [
+        ("n_samples", C.c_int), ("n_frames", C.c_int), ("fea_dim", C.c_int), ("context", C.c_int), ("n_nat", C.c_int),
+        ("fea", C.POINTER(C.c_float)), ("targ_frames", C.POINTER(C.c_float)), ("nat", C.POINTER(C.c_float)),
+        ("win_start", C.POINTER(C.c_int)), ("targ_frame", C.POINTER(C.c_int)), ("nat_row", C.POINTER(C.c_int)),
+    ]
 
 
 class BPConfig(C.Structure):
@@ -76,6 +86,9 @@ def load_library(path=None):
     lib.bp_get_weights.argtypes = [hp, fpp, fpp]
     lib.bp_get_deltas.argtypes = [hp, fpp, fpp]
     lib.bp_upload_chunk.argtypes = [hp, C.c_int, fp, fp]
+    lib.bp_upload_chunk_windows.argtypes = [hp, C.POINTER(BPWindowChunk)]
+    lib.bp_train_chunk_windows.argtypes = [hp, C.POINTER(BPWindowChunk)]
+    lib.bp_cv_chunk_windows.argtypes = [hp, C.POINTER(BPWindowChunk), fp]
     lib.bp_fill_chunk_synthetic.argtypes = [hp, C.c_int, C.c_uint64]
     lib.bp_train_resident.argtypes = [hp, C.c_int, C.c_int]
     lib.bp_sync.argtypes = [hp]
@@ -216,6 +229,41 @@ class BP_GPU(object):
         x = np.ascontiguousarray(indata, dtype=np.float32).reshape(-1, self.layersizes[0])
         t = self._in(targ, x.shape[0], self.layersizes[-1], "targ")
         self._check(self._lib.bp_upload_chunk(self._h, x.shape[0], _fp(x), _fp(t)))
+
+    # ---- on-device frame stacking (bp_window_chunk): sample i = fea[win_start[i] : win_start[i]+context] (+ nat[nat_row[i]])
+    def _windows(self, fea, targ_frames, context, win_start, targ_frame, nat=None, nat_row=None):
+        fea = np.ascontiguousarray(fea, dtype=np.float32)
+        if fea.ndim != 2:
+            self._fail("windows: fea must be [n_frames][fea_dim]")
+        tg = np.ascontiguousarray(targ_frames, dtype=np.float32).reshape(fea.shape[0], self.layersizes[-1])
+        ws = np.ascontiguousarray(win_start, dtype=np.int32)
+        tf = np.ascontiguousarray(targ_frame, dtype=np.int32)
+        c = BPWindowChunk()
+        c.n_samples, c.n_frames, c.fea_dim, c.context = int(ws.size), int(fea.shape[0]), int(fea.shape[1]), int(context)
+        c.fea, c.targ_frames = _fp(fea), _fp(tg)
+        ip = C.POINTER(C.c_int)
+        c.win_start, c.targ_frame = ws.ctypes.data_as(ip), tf.ctypes.data_as(ip)
+        keep = [fea, tg, ws, tf]
+        if nat is not None:
+            nat = np.ascontiguousarray(nat, dtype=np.float32).reshape(-1, fea.shape[1])
+            nr = np.ascontiguousarray(nat_row, dtype=np.int32)
+            c.n_nat, c.nat, c.nat_row = int(nat.shape[0]), _fp(nat), nr.ctypes.data_as(ip)
+            keep += [nat, nr]
+        return c, keep
+
+    def upload_chunk_windows(self, fea, targ_frames, context, win_start, targ_frame, nat=None, nat_row=None):
+        c, keep = self._windows(fea, targ_frames, context, win_start, targ_frame, nat, nat_row)
+        self._check(self._lib.bp_upload_chunk_windows(self._h, C.byref(c)))
+
+    def train_windows(self, fea, targ_frames, context, win_start, targ_frame, nat=None, nat_row=None):
+        c, keep = self._windows(fea, targ_frames, context, win_start, targ_frame, nat, nat_row)
+        self._check(self._lib.bp_train_chunk_windows(self._h, C.byref(c)))
+
+    def CrossValid_windows(self, fea, targ_frames, context, win_start, targ_frame, nat=None, nat_row=None):
+        c, keep = self._windows(fea, targ_frames, context, win_start, targ_frame, nat, nat_row)
+        e = C.c_float(0.0)
+        self._check(self._lib.bp_cv_chunk_windows(self._h, C.byref(c), C.byref(e)))
+        return float(e.value)
 
     def fill_chunk_synthetic(self, n_frames, seed=20260927):
         self._check(self._lib.bp_fill_chunk_synthetic(self._h, int(n_frames), int(seed)))

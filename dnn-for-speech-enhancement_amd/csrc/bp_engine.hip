@@ -49,6 +49,8 @@ struct bp_handle {
     uint32_t th_vis, th_hid;
     hipEvent_t ev0, ev1; float last_ms; int last_bunches;
     std::vector<void *> allocs;
+    // grow-only device staging of a window chunk (bp_upload_chunk_windows): raw frames, raw targets, NAT rows, tables
+    struct Raw { void *p; size_t bytes; } raw[4];
 };
 
 static uint32_t drop_threshold(float p)
@@ -85,6 +87,7 @@ extern "C" int bp_destroy(bp_handle *h)
     (void)hipSetDevice(h->cfg.device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (void *p : h->allocs) (void)hipFree(p);
+    for (auto &r : h->raw) if (r.p) (void)hipFree(r.p);
     if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -422,6 +425,77 @@ extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, cons
     return BP_OK;
 }
 
+// ---- on-device frame stacking (host counterpart: Interface.cc:757-797)
+static int raw_reserve(bp_handle *h, int which, size_t bytes)
+{
+    bp_handle::Raw &r = h->raw[which];
+    if (bytes <= r.bytes) return BP_OK;
+    if (r.p) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(r.p); r.p = nullptr; r.bytes = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipMalloc(&r.p, want);
+    if (e != hipSuccess) return fail(BP_ERR_NOMEM, std::string("hipMalloc (window staging): ") + hipGetErrorString(e));
+    r.bytes = want;
+    return BP_OK;
+}
+
+static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ, const char *who)
+{
+    if (!h || !c) return fail(BP_ERR_ARG, std::string(who) + ": null argument");
+    const int L = h->L, n = c->n_samples, D = c->fea_dim, ctx = c->context, sL = h->s[L - 1];
+    if (n < 0 || n > h->cap) return fail(BP_ERR_ARG, std::string(who) + ": n_samples exceeds chunk capacity");
+    if (D < 1 || ctx < 1 || c->n_frames < 0) return fail(BP_ERR_ARG, std::string(who) + ": bad fea_dim / context / n_frames");
+    const bool nat = c->nat != nullptr;
+    if ((long)ctx * D + (nat ? D : 0) != (long)h->s[0])
+        return fail(BP_ERR_ARG, std::string(who) + ": layersizes[0] != context*fea_dim (+ fea_dim with a NAT block)");
+    if (n > 0 && (!c->fea || !c->win_start || (with_targ && (!c->targ_frames || !c->targ_frame)) ||
+                  (nat && (!c->nat_row || c->n_nat < 1))))
+        return fail(BP_ERR_ARG, std::string(who) + ": null table");
+    for (int i = 0; i < n; ++i) {
+        if (c->win_start[i] < 0 || c->win_start[i] + ctx > c->n_frames)
+            return fail(BP_ERR_ARG, std::string(who) + ": win_start out of range");
+        if (with_targ && (c->targ_frame[i] < 0 || c->targ_frame[i] >= c->n_frames))
+            return fail(BP_ERR_ARG, std::string(who) + ": targ_frame out of range");
+        if (nat && (c->nat_row[i] < 0 || c->nat_row[i] >= c->n_nat))
+            return fail(BP_ERR_ARG, std::string(who) + ": nat_row out of range");
+    }
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (n > 0) {
+        const size_t fea_b = (size_t)c->n_frames * D * 4, tg_b = with_targ ? (size_t)c->n_frames * sL * 4 : 0;
+        const size_t nat_b = nat ? (size_t)c->n_nat * D * 4 : 0, idx_b = (size_t)n * 4;
+        int r;
+        if ((r = raw_reserve(h, 0, fea_b)) != BP_OK || (r = raw_reserve(h, 1, tg_b)) != BP_OK ||
+            (r = raw_reserve(h, 2, nat_b)) != BP_OK || (r = raw_reserve(h, 3, 3 * idx_b)) != BP_OK)
+            return r;
+        float *d_fea = (float *)h->raw[0].p, *d_tg = (float *)h->raw[1].p, *d_nat = (float *)h->raw[2].p;
+        int *d_ws = (int *)h->raw[3].p, *d_tf = d_ws + n, *d_nr = d_tf + n;
+        HIPCHK(hipMemcpyAsync(d_fea, c->fea, fea_b, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d_ws, c->win_start, idx_b, hipMemcpyHostToDevice, h->stream));
+        if (nat) {
+            HIPCHK(hipMemcpyAsync(d_nat, c->nat, nat_b, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d_nr, c->nat_row, idx_b, hipMemcpyHostToDevice, h->stream));
+        }
+        const int yb = (h->ld[0] + 1023) / 1024 > 0 ? (h->ld[0] + 1023) / 1024 : 1;
+        hipLaunchKernelGGL(bp_expand_windows, dim3((unsigned)n, (unsigned)yb), dim3(256), 0, h->stream, h->in, h->ld[0], h->s[0],
+                           d_fea, D, ctx * D, nat ? d_nat : (const float *)nullptr, d_ws, nat ? d_nr : (const int *)nullptr, n);
+        HIPCHK(hipGetLastError());
+        if (with_targ) {
+            HIPCHK(hipMemcpyAsync(d_tg, c->targ_frames, tg_b, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d_tf, c->targ_frame, idx_b, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(bp_gather_rows, dim3((unsigned)n, 1), dim3(256), 0, h->stream, h->targ, h->ld[L - 1], sL, d_tg, d_tf, n);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));       // the caller may overwrite its buffers as soon as we return
+    }
+    h->chunk_frames = n;
+    h->mask_lo = h->mask_hi = -1;
+    return BP_OK;
+}
+
+extern "C" int bp_upload_chunk_windows(bp_handle *h, const bp_window_chunk *c)
+{
+    return upload_windows(h, c, true, "bp_upload_chunk_windows");
+}
+
 extern "C" int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
@@ -480,6 +554,15 @@ extern "C" int bp_train_chunk(bp_handle *h, int n_frames, const float *in, const
     if (n_frames % h->B)
         printf("this bunch has only %d samples and is ignored.\n", n_frames % h->B);   // BP_GPU.cu:317
     return bp_train_resident(h, 0, n_frames);
+}
+
+extern "C" int bp_train_chunk_windows(bp_handle *h, const bp_window_chunk *c)
+{
+    int r = upload_windows(h, c, true, "bp_train_chunk_windows");
+    if (r != BP_OK) return r;
+    if (c->n_samples % h->B)
+        printf("this bunch has only %d samples and is ignored.\n", c->n_samples % h->B);   // BP_GPU.cu:317
+    return bp_train_resident(h, 0, c->n_samples);
 }
 
 // ------------------------------------------------------------------ data-parallel split
@@ -706,6 +789,34 @@ extern "C" int bp_cv_chunk(bp_handle *h, int n_frames, const float *in, const fl
                 const float e = h->host_out[(size_t)j * ldL + d] - t[(size_t)j * sL + d];
                 squared_err = squared_err + e * e;
             }
+    }
+    *sq_err_sum = squared_err;
+    return BP_OK;
+}
+
+extern "C" int bp_cv_chunk_windows(bp_handle *h, const bp_window_chunk *c, float *sq_err_sum)
+{
+    if (!sq_err_sum) return fail(BP_ERR_ARG, "bp_cv_chunk_windows: null argument");
+    int r = upload_windows(h, c, false, "bp_cv_chunk_windows");
+    if (r != BP_OK) return r;
+    const int L = h->L, sL = h->s[L - 1], ldL = h->ld[L - 1], n = c->n_samples;
+    if (n > 0 && (!c->targ_frames || !c->targ_frame)) return fail(BP_ERR_ARG, "bp_cv_chunk_windows: null targets");
+    for (int i = 0; i < n; ++i)
+        if (c->targ_frame[i] < 0 || c->targ_frame[i] >= c->n_frames) return fail(BP_ERR_ARG, "bp_cv_chunk_windows: targ_frame out of range");
+    float squared_err = 0.0f;
+    for (int i = 0; i < n; i += h->B) {                  // partial bunch processed (BP_GPU.cu:450-453)
+        const int fb = h->B > n - i ? n - i : h->B;
+        r = forward_bunch(h, i, fb);
+        if (r != BP_OK) return r;
+        HIPCHK(hipMemcpyAsync(h->host_out, h->out_dev, (size_t)fb * ldL * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int j = 0; j < fb; ++j) {                   // fp32, frame-major / bin-minor (BP_GPU.cu:458-467)
+            const float *t = c->targ_frames + (size_t)c->targ_frame[i + j] * sL;
+            for (int d = 0; d < sL; ++d) {
+                const float e = h->host_out[(size_t)j * ldL + d] - t[d];
+                squared_err = squared_err + e * e;
+            }
+        }
     }
     *sq_err_sum = squared_err;
     return BP_OK;

@@ -854,6 +854,36 @@ __global__ __launch_bounds__(256, K::MIN_WG) void bp_gemm_multi(const MultiArgs 
 }
 
 // ------------------------------------------------------------------ small kernels
+// On-device frame stacking (include/bp_c_api.h, bp_window_chunk; Interface.cc:757-790 does this on the
+// host): row i of the chunk = `win` consecutive floats of the raw frame matrix starting at frame
+// win_start[i] (the context window is contiguous in memory), then the sentence's noise-aware block,
+// then zero padding up to ld.  blockIdx.x = sample, blockIdx.y x threads sweep the columns (coalesced 4-byte
+// accesses: raw rows of 257 floats are not 16-byte aligned).
+__global__ void bp_expand_windows(float *out, int ld, int width, const float *fea, int fea_dim, int win,
+                                  const float *nat, const int *win_start, const int *nat_row, int n_samples)
+{
+    const int i = blockIdx.x;
+    if (i >= n_samples) return;
+    const float *src = fea + (size_t)win_start[i] * fea_dim;
+    const float *nsrc = nat ? nat + (size_t)nat_row[i] * fea_dim : nullptr;
+    float *dst = out + (size_t)i * ld;
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < ld; c += gridDim.y * blockDim.x) {
+        float v = 0.0f;
+        if (c < win) v = src[c];
+        else if (c < width) v = nsrc[c - win];
+        dst[c] = v;
+    }
+}
+// targ[i] = targ_frames[targ_frame[i]] (Interface.cc:792-797), zero padded to ld
+__global__ void bp_gather_rows(float *out, int ld, int width, const float *rows, const int *row_of, int n_samples)
+{
+    const int i = blockIdx.x;
+    if (i >= n_samples) return;
+    const float *src = rows + (size_t)row_of[i] * width;
+    float *dst = out + (size_t)i * ld;
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < ld; c += gridDim.y * blockDim.x) dst[c] = c < width ? src[c] : 0.0f;
+}
+
 // Visible-layer dropout of the resident chunk (BP_GPU.cu:536-539 masks the device copy of the
 // chunk in place; here the masked frames go to a second buffer so the chunk stays reusable).
 // One thread = one unit x 4 consecutive chunk rows.

@@ -6,12 +6,17 @@
 // (finetune_DNN_speech_enhancement_dropout_NAT.pl) can call this binary unchanged.
 //
 // Extra optional keys (defaults = live reference behaviour): activation=relu|sigmoid,
-// momentum_rule=live|classic, seed=<u64> (dropout stream), device=<ordinal>.
+// momentum_rule=live|classic, seed=<u64> (dropout stream), device=<ordinal>;
+// stack=device|host (default device: raw frames + index tables go to the GPU, which builds the context
+// windows -- 11x less host work and upload, identical samples; host = the reference's Readchunk layout),
+// prefetch=1|0 (default 1: the next chunk is read while the current one is uploaded / trained).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
+#include <functional>
+#include <future>
 #include <string>
 #include <vector>
 
@@ -25,6 +30,45 @@ struct Params {
     int seed = 0, numlayers = 0, layersizes[MAXLAYER] = {0};
     float momentum = 0, weightcost = 0, lrate = 0, visible_omit = 0, hid_omit = 0;
     float wmin = -0.1f, wmax = 0.1f, bmin = -0.1f, bmax = 0.1f;          // Interface.cc:79-82
+    bool stack_on_device = true, prefetch = true;
+};
+
+typedef bp::PfileReader::WindowChunk WindowChunk;
+static bp_window_chunk describe(const WindowChunk &w, int context)
+{
+    bp_window_chunk c;
+    memset(&c, 0, sizeof(c));
+    c.n_samples = w.n_samples; c.n_frames = w.n_frames; c.fea_dim = w.fea_dim; c.context = context;
+    c.n_nat = w.n_nat();
+    c.fea = w.fea.data(); c.targ_frames = w.targ.data(); c.nat = w.nat.empty() ? nullptr : w.nat.data();
+    c.win_start = w.win_start.data(); c.targ_frame = w.targ_frame.data(); c.nat_row = w.nat_row.empty() ? nullptr : w.nat_row.data();
+    return c;
+}
+
+// Chunks of one plan, in the given order, read one ahead of the consumer on a helper thread (reads stay strictly
+// sequential, so the lrand48 stream is consumed in the reference's order).
+class ChunkStream {
+public:
+    ChunkStream(bp::PfileReader &r, const bp::PfileReader::Plan &p, const std::vector<int> &order, bool shuffle, bool prefetch)
+        : r_(r), p_(p), order_(order), shuffle_(shuffle), prefetch_(prefetch) { if (prefetch_ && !order_.empty()) start(0); }
+    const WindowChunk &get(int i)
+    {
+        if (prefetch_) {
+            fut_.get();
+            if (i + 1 < (int)order_.size()) start(i + 1);
+        } else {
+            r_.read_chunk_windows(p_, order_[i], shuffle_, slot_[i & 1]);
+        }
+        return slot_[i & 1];
+    }
+private:
+    void start(int i)
+    {
+        fut_ = std::async(std::launch::async, [this, i] { r_.read_chunk_windows(p_, order_[i], shuffle_, slot_[i & 1]); });
+    }
+    bp::PfileReader &r_; const bp::PfileReader::Plan &p_; std::vector<int> order_; bool shuffle_, prefetch_;
+    WindowChunk slot_[2];
+    std::future<void> fut_;
 };
 
 static void parse_range(const std::string &r, int *st, int *en, FILE *log)
@@ -76,6 +120,8 @@ int main(int argc, char **argv)
         else if (k == "momentum_rule") setenv("BP_MOMENTUM_RULE", v.c_str(), 1);
         else if (k == "seed") setenv("BP_SEED", v.c_str(), 1);
         else if (k == "device") setenv("BP_DEVICE", v.c_str(), 1);
+        else if (k == "stack") P.stack_on_device = (v != "host");
+        else if (k == "prefetch") P.prefetch = atoi(v.c_str()) != 0;
         // unknown names are silently ignored, as in the reference (e.g. the .pl passes numlayers=)
     }
     FILE *log = fopen(P.log_file.c_str(), "wt");
@@ -149,7 +195,10 @@ int main(int argc, char **argv)
         fprintf(log, "Init weight file loaded.\n");
     }
     fflush(log);
-    std::vector<float> indata((size_t)P.layersizes[0] * P.traincache), targ((size_t)P.layersizes[L - 1] * P.traincache);
+    std::vector<float> indata, targ;           // stacked host copies, only for stack=host
+    if (!P.stack_on_device) {
+        indata.resize((size_t)P.layersizes[0] * P.traincache); targ.resize((size_t)P.layersizes[L - 1] * P.traincache);
+    }
 
     // ---- BPtrain.cc:31-96
     BP_GPU *TrainObj = new BP_GPU(P.gpu_used, L, P.layersizes, P.bunchsize, P.lrate, P.momentum, P.weightcost, weights, bias,
@@ -163,14 +212,30 @@ int main(int argc, char **argv)
     std::vector<int> chunk_index(nchunks);
     for (int i = 0; i < nchunks; ++i) chunk_index[i] = i;
     bp::PfileReader::rand_index(chunk_index.data(), nchunks);           // BPtrain.cc:47
-    for (int i = 0; i < nchunks; ++i) {
-        const int n = reader.read_chunk(tp, chunk_index[i], true, indata.data(), targ.data());
-        fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, n);
-        fflush(log);
-        TrainObj->train(n, indata.data(), targ.data());    // returns once the chunk is on the device: the next
-    }                                                      // Readchunk overlaps the GPU's work on this one
+    struct timespec ts0, ts1;
+    clock_gettime(CLOCK_MONOTONIC, &ts0);
+    {
+        ChunkStream chunks(reader, tp, chunk_index, true, P.prefetch);
+        for (int i = 0; i < nchunks; ++i) {
+            const WindowChunk &w = chunks.get(i);           // (the read of chunk i+1 is now running behind us)
+            fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, w.n_samples);
+            fflush(log);
+            if (P.stack_on_device) {
+                TrainObj->train_windows(describe(w, P.fea_context));
+            } else {
+                reader.expand(w, indata.data(), targ.data());
+                TrainObj->train(w.n_samples, indata.data(), targ.data());
+            }                                               // both return once the chunk is on the device; the
+        }                                                   // GPU works on it while the next one is prepared
+    }
     printf("begin to write weights\n");
-    TrainObj->returnWeights(weights, bias);
+    TrainObj->returnWeights(weights, bias);                 // (waits for the last chunk's bunches)
+    clock_gettime(CLOCK_MONOTONIC, &ts1);
+    {
+        const double dt = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
+        fprintf(log, "Training pass: %u samples in %.3f s (%.0f frames/s, reader + upload + GPU).\n", tp.total_samples, dt,
+                dt > 0 ? tp.total_samples / dt : 0.0);
+    }
     fprintf(log, "Saving weights to file...\n");
     bp::write_weights(fp_out, L, P.layersizes, weights, bias);
     fclose(fp_out);
@@ -183,10 +248,20 @@ int main(int argc, char **argv)
     const bp::PfileReader::Plan cp = reader.plan(st, en);
     fprintf(log, "Get cv chunk info over: CV sentences have %d chunks, %d samples.\n", (int)cp.chunk_frame_st.size(), (int)cp.total_samples);
     float squared_err = 0.0f;
-    for (int i = 0; i < (int)cp.chunk_frame_st.size(); ++i) {
-        const int n = reader.read_chunk(cp, i, false, indata.data(), targ.data());
-        printf("cur_chunk_samples=%d\n", n);
-        squared_err += TrainObj->CrossValid(n, indata.data(), targ.data());
+    {
+        std::vector<int> cv_order(cp.chunk_frame_st.size());
+        for (size_t i = 0; i < cv_order.size(); ++i) cv_order[i] = (int)i;
+        ChunkStream chunks(reader, cp, cv_order, false, P.prefetch);
+        for (int i = 0; i < (int)cv_order.size(); ++i) {
+            const WindowChunk &w = chunks.get(i);
+            printf("cur_chunk_samples=%d\n", w.n_samples);
+            if (P.stack_on_device) {
+                squared_err += TrainObj->CrossValid_windows(describe(w, P.fea_context));
+            } else {
+                reader.expand(w, indata.data(), targ.data());
+                squared_err += TrainObj->CrossValid(w.n_samples, indata.data(), targ.data());
+            }
+        }
     }
     const float cvacc = squared_err / cp.total_samples;                  // BPtrain.cc:84
     fprintf(log, "CV over. squared error: %f\n", cvacc);

@@ -126,9 +126,11 @@ void PfileReader::rand_index(int *vec, int len)
     }
 }
 
-int PfileReader::read_chunk(const Plan &p, int ci, bool shuffle, float *in, float *targ)
+int PfileReader::WindowChunk::n_nat() const { return fea_dim > 0 ? (int)(nat.size() / (size_t)fea_dim) : 0; }
+
+int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowChunk &w)
 {
-    const int D = cfg_.fea_dim, ctx = cfg_.fea_context, OD = cfg_.out_dim, s0 = cfg_.input_dim;
+    const int D = cfg_.fea_dim, ctx = cfg_.fea_context, OD = cfg_.out_dim;
     const int nchunks = (int)p.chunk_frame_st.size();
     const int frame_st = p.chunk_frame_st[ci];
     int frames_need, samples;
@@ -139,29 +141,36 @@ int PfileReader::read_chunk(const Plan &p, int ci, bool shuffle, float *in, floa
         frames_need = p.chunk_frame_st[ci + 1] - frame_st;
         samples = cfg_.traincache;
     }
-    std::vector<int> sample_index(samples > 0 ? samples : 0);
-    for (int i = 0; i < samples; ++i) sample_index[i] = i;
+    w.fea_dim = D;
+    w.n_samples = samples > 0 ? samples : 0;
+    w.n_frames = 0;
+    w.nat.clear();
+    w.win_start.assign(w.n_samples, 0); w.targ_frame.assign(w.n_samples, 0); w.nat_row.assign(nat_ ? w.n_samples : 0, 0);
+    std::vector<int> sample_index(w.n_samples);
+    for (int i = 0; i < w.n_samples; ++i) sample_index[i] = i;
     if (shuffle) rand_index(sample_index.data(), samples);
-    if (frames_need <= 0 || samples <= 0) return samples > 0 ? samples : 0;
+    if (frames_need <= 0 || samples <= 0) return w.n_samples;
+    w.n_frames = frames_need;
 
     // ---- features: big-endian records {sent_id, frame_id, feat[D]} -> mean/variance normalised floats
-    std::vector<uint32_t> raw((size_t)frames_need * (D + 2));
+    std::vector<uint32_t> &raw = raw_;
+    raw.resize((size_t)frames_need * (D + 2));
     if (fseek(fp_data_, PFILE_HEADER_SIZE + (long)frame_st * (long)sizeof(float) * (D + 2), SEEK_SET) != 0)
         die("data pfile cannot fseek to chunk %d.", ci);
     if (fread(raw.data(), sizeof(float) * (D + 2), frames_need, fp_data_) != (size_t)frames_need)
         die("data pfile: short read in chunk %d.", ci);
     const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
-    std::vector<float> fea((size_t)frames_need * D);
+    w.fea.resize((size_t)frames_need * D);
     for (int i = 0; i < frames_need; ++i)
         for (int j = 0; j < D; ++j) {
-            const uint32_t w = bswap(raw[(size_t)i * (D + 2) + 2 + j]);
-            float v; memcpy(&v, &w, 4);
+            const uint32_t x = bswap(raw[(size_t)i * (D + 2) + 2 + j]);
+            float v; memcpy(&v, &x, 4);
             v -= mean_[j];
             v *= dvar_[j];
-            fea[(size_t)i * D + j] = v;
+            w.fea[(size_t)i * D + j] = v;
         }
     // ---- targets (not normalised, Interface.cc:815-816)
-    std::vector<float> tg((size_t)frames_need * OD);
+    w.targ.resize((size_t)frames_need * OD);
     if (fseek(fp_targ_, PFILE_HEADER_SIZE + (long)frame_st * (long)sizeof(float) * (OD + 2), SEEK_SET) != 0)
         die("targ pfile cannot fseek to chunk %d.", ci);
     raw.resize((size_t)frames_need * (OD + 2));
@@ -169,8 +178,8 @@ int PfileReader::read_chunk(const Plan &p, int ci, bool shuffle, float *in, floa
         die("targ pfile: short read in chunk %d.", ci);
     for (int i = 0; i < frames_need; ++i)
         for (int j = 0; j < OD; ++j) {
-            const uint32_t w = bswap(raw[(size_t)i * (OD + 2) + 2 + j]);
-            memcpy(&tg[(size_t)i * OD + j], &w, 4);
+            const uint32_t x = bswap(raw[(size_t)i * (OD + 2) + 2 + j]);
+            memcpy(&w.targ[(size_t)i * OD + j], &x, 4);
         }
 
     // ---- samples: per sentence segment inside the chunk, ctx stacked frames (oldest first) [+ NAT block]
@@ -179,33 +188,61 @@ int PfileReader::read_chunk(const Plan &p, int ci, bool shuffle, float *in, floa
         int seg;
         if (frames_before_sent_[cur_sent] > frames_need + frame_st) seg = frames_need - frames_processed;
         else seg = frames_before_sent_[cur_sent] - cur_frame_id;
+        int nat_id = -1;
         for (int j = 0; j <= seg - ctx && cur_sample < samples; ++j) {
-            float *row = in + (size_t)sample_index[cur_sample] * s0;
-            for (int i = 0; i < ctx; ++i)
-                memcpy(row + (size_t)i * D, &fea[(size_t)(frames_processed + j + i) * D], sizeof(float) * D);
+            const int pos = sample_index[cur_sample];
+            w.win_start[pos] = frames_processed + j;
             if (nat_) {
-                // noise-aware training: mean of the segment's first 6 normalised frames, summed left to right
-                // and divided by 6.0f (Interface.cc:776-779, generalised from the literal 129 to fea_dim)
-                for (int k = 0; k < D; ++k) {
-                    float s = 0.0f;
-                    for (int f = 0; f < 6; ++f) {
-                        int fr = frames_processed + f;
-                        if (fr >= frames_need) fr = frames_need - 1;          // (the reference reads past its buffer here)
-                        s = f == 0 ? fea[(size_t)fr * D + k] : s + fea[(size_t)fr * D + k];
+                if (nat_id < 0) {
+                    // noise-aware training: mean of the segment's first 6 normalised frames, summed left to right
+                    // and divided by 6.0f (Interface.cc:776-779, generalised from the literal 129 to fea_dim)
+                    nat_id = w.n_nat();
+                    w.nat.resize(w.nat.size() + (size_t)D);
+                    float *nrow = &w.nat[(size_t)nat_id * D];
+                    for (int k = 0; k < D; ++k) {
+                        float s = 0.0f;
+                        for (int f = 0; f < 6; ++f) {
+                            int fr = frames_processed + f;
+                            if (fr >= frames_need) fr = frames_need - 1;          // (the reference reads past its buffer here)
+                            s = f == 0 ? w.fea[(size_t)fr * D + k] : s + w.fea[(size_t)fr * D + k];
+                        }
+                        nrow[k] = s / 6.0f;
                     }
-                    row[(size_t)ctx * D + k] = s / 6.0f;
                 }
+                w.nat_row[pos] = nat_id;
             }
             int tf = frames_processed + j + cfg_.targ_offset;
             if (tf >= frames_need) tf = frames_need - 1;
-            memcpy(targ + (size_t)sample_index[cur_sample] * OD, &tg[(size_t)tf * OD], sizeof(float) * OD);
+            w.targ_frame[pos] = tf;
             ++cur_sample;
         }
         cur_frame_id = frames_before_sent_[cur_sent];
         ++cur_sent;
         frames_processed += seg;
     }
-    return samples;
+    // samples the segment walk did not reach (cannot happen with a consistent plan) keep window 0: the stacked
+    // reader would have left stale rows there
+    return w.n_samples;
+}
+
+void PfileReader::expand(const WindowChunk &w, float *in, float *targ) const
+{
+    const int D = cfg_.fea_dim, ctx = cfg_.fea_context, OD = cfg_.out_dim, s0 = cfg_.input_dim;
+    if (w.n_frames <= 0) return;
+    for (int i = 0; i < w.n_samples; ++i) {
+        float *row = in + (size_t)i * s0;
+        memcpy(row, &w.fea[(size_t)w.win_start[i] * D], sizeof(float) * (size_t)ctx * D);
+        if (nat_) memcpy(row + (size_t)ctx * D, &w.nat[(size_t)w.nat_row[i] * D], sizeof(float) * D);
+        memcpy(targ + (size_t)i * OD, &w.targ[(size_t)w.targ_frame[i] * OD], sizeof(float) * OD);
+    }
+}
+
+int PfileReader::read_chunk(const Plan &p, int ci, bool shuffle, float *in, float *targ)
+{
+    WindowChunk w;
+    const int n = read_chunk_windows(p, ci, shuffle, w);
+    expand(w, in, targ);
+    return n;
 }
 
 }  // namespace bp

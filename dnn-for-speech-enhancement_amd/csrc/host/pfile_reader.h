@@ -7,6 +7,7 @@
 // so this reader is pinned by an independent numpy restatement (tests/test_pfile_reader.py) and
 // not by reference-generated fixtures.
 #pragma once
+#include <stdint.h>
 #include <stdio.h>
 #include <string>
 #include <vector>
@@ -33,6 +34,22 @@ public:
     // written at a shuffled position when `shuffle` (train) else in order (CV).  in: [samples][input_dim],
     // targ: [samples][out_dim].
     int read_chunk(const Plan &p, int chunk_index, bool shuffle, float *in, float *targ);
+    // The same chunk WITHOUT the host-side stacking ("next" row N3): raw normalised frames + raw target frames +
+    // one NAT row per sentence segment + per-sample tables.  Sample i (already at its shuffled position) is
+    //   in[i]   = fea[win_start[i] .. win_start[i]+ctx) ++ (nat ? nat[nat_row[i]] : {})
+    //   targ[i] = targ[targ_frame[i]]
+    // read_chunk() is expand(read_chunk_windows()), so both produce identical samples by construction; the
+    // library expands the same tables on the device (bp_train_chunk_windows).  Returns the number of samples.
+    struct WindowChunk {
+        int n_samples = 0, n_frames = 0;
+        std::vector<float> fea, targ, nat;                    // [n_frames][fea_dim], [n_frames][out_dim], [n_nat][fea_dim]
+        std::vector<int> win_start, targ_frame, nat_row;      // [n_samples]
+        int n_nat() const;
+        int fea_dim = 0;
+    };
+    int read_chunk_windows(const Plan &p, int chunk_index, bool shuffle, WindowChunk &out);
+    // host-side expansion of a window chunk into stacked rows (what Interface::Readchunk leaves in its buffers)
+    void expand(const WindowChunk &w, float *in, float *targ) const;
     unsigned total_frames() const { return total_frames_; }
     unsigned total_sents() const { return total_sents_; }
     const std::vector<int> &frames_before_sent() const { return frames_before_sent_; }
@@ -46,6 +63,7 @@ private:
     unsigned total_frames_ = 0, total_sents_ = 0;
     std::vector<int> frames_before_sent_;
     std::vector<float> mean_, dvar_;
+    std::vector<uint32_t> raw_;       // file-record scratch, kept across chunks
     bool nat_ = false;
 };
 

@@ -15,6 +15,7 @@
  *     per GPU through bp_config.global_bunchsize / rank_frame_offset.
  *   - train_bunch_single / train_bunch_multi / cv_bunch_single take DEVICE pointers in the
  *     reference and are only called from inside the class; they are not re-exported.
+ *   - train_windows / CrossValid_windows are additions (on-device frame stacking).
  *   - optional behaviour switches the reference has only as source edits can be set through
  *     environment variables before construction: BP_ACTIVATION=sigmoid|relu,
  *     BP_MOMENTUM_RULE=classic|live, BP_SEED=<u64>, BP_DEVICE=<ordinal>.
@@ -72,6 +73,15 @@ public:
     {
         float e = 0.0f;
         check(bp_cv_chunk(handle_, n_frames, in, targ, &e));
+        return e;
+    }
+    /* Extensions (no reference counterpart): the same two calls with the frame stacking done on the
+     * device from raw frames + index tables (bp_window_chunk, bp_c_api.h). */
+    void train_windows(const bp_window_chunk &c) { check(bp_train_chunk_windows(handle_, &c)); }
+    float CrossValid_windows(const bp_window_chunk &c)
+    {
+        float e = 0.0f;
+        check(bp_cv_chunk_windows(handle_, &c, &e));
         return e;
     }
     /* BP_GPU.h:60 / BP_GPU.cu:910-923 */

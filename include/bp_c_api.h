@@ -116,6 +116,34 @@ int bp_train_resident(bp_handle *h, int first_frame, int n_frames);
 int bp_sync(bp_handle *h);
 
 /* ------------------------------------------------------------------------------------
+ * On-device frame stacking.  The reference's reader materialises every
+ * sample on the host as `context` consecutive normalised frames [+ the noise-aware block]
+ * (Interface.cc:757-790) and uploads context x the raw volume.  Here the caller hands over the
+ * RAW normalised frames of the chunk once plus three index tables; the library expands them
+ * into the resident chunk on the device.  Row i of the expanded chunk is
+ *     in[i]   = fea[win_start[i] .. win_start[i]+context)   (context*fea_dim contiguous floats)
+ *               ++ nat[nat_row[i]]                          (fea_dim floats, only when nat != NULL)
+ *     targ[i] = targ_frames[targ_frame[i]]                  (layersizes[L-1] floats)
+ * i.e. bit-identical to what bp_upload_chunk would have received.  layersizes[0] must equal
+ * context*fea_dim (+ fea_dim with a NAT block).  The caller may overwrite everything as soon
+ * as the call returns. */
+typedef struct bp_window_chunk {
+    int n_samples;             /* rows of the expanded chunk (<= chunk capacity) */
+    int n_frames;              /* raw frames in fea / targ_frames */
+    int fea_dim, context;
+    int n_nat;                 /* rows of nat (0 when nat == NULL) */
+    const float *fea;          /* [n_frames][fea_dim], already mean/variance normalised */
+    const float *targ_frames;  /* [n_frames][layersizes[L-1]] */
+    const float *nat;          /* [n_nat][fea_dim] or NULL */
+    const int *win_start;      /* [n_samples] first raw frame of the window */
+    const int *targ_frame;     /* [n_samples] raw frame whose target row is used */
+    const int *nat_row;        /* [n_samples] or NULL */
+} bp_window_chunk;
+int bp_upload_chunk_windows(bp_handle *h, const bp_window_chunk *c);             /* then bp_train_resident etc. */
+int bp_train_chunk_windows(bp_handle *h, const bp_window_chunk *c);              /* = BP_GPU::train on the expanded chunk */
+int bp_cv_chunk_windows(bp_handle *h, const bp_window_chunk *c, float *sq_err_sum); /* = BP_GPU::CrossValid */
+
+/* ------------------------------------------------------------------------------------
  * Data-parallel split of train_bunch_single (the reference's dead train_bunch_multi,
  * BP_GPU.cu:775-908, is the semantics donor): gradients of one local bunch are written to a
  * flat fp32 device buffer [W_1 | b_1 | W_2 | b_2 ...] (padded layout, see bp_grad_layout),

@@ -32,8 +32,9 @@ def test_bptrain_links_and_reports_errors_like_the_reference(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("act,rule", [("relu", "live"), ("sigmoid", "classic")])
-def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule):
+@pytest.mark.parametrize("act,rule,stack", [("relu", "live", "device"), ("sigmoid", "classic", "host"),
+                                            ("relu", "live", "host-noprefetch")])
+def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule, stack):
     D, ctx, toff, seed, cache, B = 33, 3, 1, 345, 50, 16
     ls = [D * (ctx + 1), 64, D]                                                   # NAT block appended
     lens = [30, 22, 41, 8, 27, 35, 19, 26, 33, 24]
@@ -54,6 +55,9 @@ def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule):
             "bunchsize=%d" % B, "gpu_used=1", "init_randem_seed=%d" % seed, "momentum=0.5", "weightcost=0.0", "lrate=1",
             "visible_omit=0.0", "hid_omit=0.0", "numlayers=3", "layersizes=%s" % ",".join(map(str, ls)),
             "activation=" + act, "momentum_rule=" + rule]
+    # frame stacking on the device (default) or on the host (the reference's Readchunk layout), with / without the
+    # read-ahead thread: the same samples reach the trainer in every mode
+    args += {"device": [], "host": ["stack=host"], "host-noprefetch": ["stack=host", "prefetch=0"]}[stack]
     r = subprocess.run([_exe()] + args, capture_output=True, text=True)
     assert r.returncode == 1, r.stdout + r.stderr                                  # BPtrain.cc:100
     assert "all finish!" in r.stdout
@@ -87,5 +91,33 @@ def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule):
     assert m and abs(float(m.group(1)) - sq / ctotal) < 1e-3 * (sq / ctotal) + 1e-5
     for needle in ("parameters input:", "Please check...", "Norm file loaded.", "Init weight file loaded.",
                    "Get chunk info over: Training sentences have %d chunks, %d samples." % (len(starts), total),
-                   "Saving over.", "Starting CV.", "Total cost time:"):
+                   "Saving over.", "Starting CV.", "Total cost time:", "Training pass: %d samples in" % total):
         assert needle in log_lines, needle
+
+
+@pytest.mark.gpu
+def test_bptrain_device_and_host_stacking_write_identical_weights(tmp_path):
+    """stack=device (raw frames + index tables, windows built by the GPU) and stack=host (stacked rows uploaded) are
+    the same computation: byte-identical weight files and CV lines, with dropout on."""
+    D, ctx, cache, B = 20, 5, 64, 16
+    ls = [D * (ctx + 1), 48, 32, D]
+    lens = [40, 9, 33, 4, 28, 37, 21, 30]
+    rs = np.random.default_rng(4)
+    n = sum(lens)
+    fea = rs.normal(size=(n, D)).astype(np.float32); tg = rs.normal(size=(n, D)).astype(np.float32)
+    PU.write_pfile(str(tmp_path / "f"), lens, fea); PU.write_pfile(str(tmp_path / "t"), lens, tg)
+    PU.write_norm(str(tmp_path / "n"), fea.mean(0).astype(np.float32), (1.0 / fea.std(0)).astype(np.float32))
+    outs = {}
+    for mode in ("device", "host"):
+        args = ["fea_file=%s" % (tmp_path / "f"), "targ_file=%s" % (tmp_path / "t"), "norm_file=%s" % (tmp_path / "n"),
+                "outwts_file=%s" % (tmp_path / ("w." + mode)), "log_file=%s" % (tmp_path / ("log." + mode)),
+                "train_sent_range=0-5", "cv_sent_range=6-7", "fea_dim=%d" % D, "fea_context=%d" % ctx, "targ_offset=2",
+                "dropoutflag=1", "traincache=%d" % cache, "bunchsize=%d" % B, "gpu_used=1", "init_randem_seed=7",
+                "momentum=0.5", "weightcost=0.0001", "lrate=0.5", "visible_omit=0.1", "hid_omit=0.2",
+                "layersizes=%s" % ",".join(map(str, ls)), "seed=99", "stack=" + mode]
+        r = subprocess.run([_exe()] + args, capture_output=True, text=True)
+        assert r.returncode == 1, r.stdout + r.stderr
+        log = open(tmp_path / ("log." + mode)).read()
+        outs[mode] = (open(tmp_path / ("w." + mode), "rb").read(), re.search(r"CV over\. squared error: (\S+)", log).group(1))
+    assert outs["device"][0] == outs["host"][0] and len(outs["device"][0]) > 1000
+    assert outs["device"][1] == outs["host"][1]

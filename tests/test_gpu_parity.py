@@ -268,3 +268,65 @@ def test_full_size_properties(pkg):
     for l in range(1, len(ls)):
         assert relerr(w0[l], wa[l]) < 1e-5 and relerr(b0[l], ba[l]) < 1e-5
     r0.close(); r1.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# on-device frame stacking (bp_window_chunk): bit-identical to uploading stacked rows
+def _window_case(rs, nat, n_frames=300, D=21, ctx=5, od=17, n=200):
+    fea = rs.normal(size=(n_frames, D)).astype(np.float32)
+    tg = rs.normal(size=(n_frames, od)).astype(np.float32)
+    ws = rs.integers(0, n_frames - ctx + 1, size=n).astype(np.int32)
+    tf = rs.integers(0, n_frames, size=n).astype(np.int32)
+    natm = rs.normal(size=(4, D)).astype(np.float32) if nat else None
+    nr = rs.integers(0, 4, size=n).astype(np.int32) if nat else None
+    rows = np.stack([fea[w:w + ctx].reshape(-1) for w in ws])
+    if nat:
+        rows = np.concatenate([rows, natm[nr]], axis=1)
+    return fea, tg, ws, tf, natm, nr, np.ascontiguousarray(rows), np.ascontiguousarray(tg[tf])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nat", [False, True])
+def test_window_chunk_equals_stacked_chunk(pkg, nat):
+    rs = np.random.default_rng(31)
+    D, ctx, od, B = 21, 5, 17, 32
+    fea, tg, ws, tf, natm, nr, rows, trows = _window_case(rs, nat, D=D, ctx=ctx, od=od)
+    ls = [rows.shape[1], 70, od]
+    W = [None] + [(rs.normal(size=(ls[l - 1], ls[l])) * 0.1).astype(np.float32) for l in (1, 2)]
+    b = [None] + [(rs.normal(size=ls[l]) * 0.1).astype(np.float32) for l in (1, 2)]
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=5)
+    g1 = pkg.BP_GPU(1, 3, ls, B, 0.5, 0.5, 1e-4, W, b, **kw)
+    g2 = pkg.BP_GPU(1, 3, ls, B, 0.5, 0.5, 1e-4, W, b, **kw)
+    for _ in range(2):                                           # two chunks: staging buffers are reused
+        g1.train(rows.shape[0], rows, trows)
+        g2.train_windows(fea, tg, ctx, ws, tf, natm, nr)
+    e1 = g1.CrossValid(rows.shape[0], rows, trows)
+    e2 = g2.CrossValid_windows(fea, tg, ctx, ws, tf, natm, nr)
+    assert e1 == e2
+    for g in (g1, g2):
+        g.W_, g.b_ = [None] + [np.zeros_like(W[l]) for l in (1, 2)], [None] + [np.zeros_like(b[l]) for l in (1, 2)]
+        g.returnWeights(g.W_, g.b_)
+    for l in (1, 2):
+        assert np.array_equal(g1.W_[l], g2.W_[l]) and np.array_equal(g1.b_[l], g2.b_[l])
+    assert not np.array_equal(g1.W_[1], W[1])
+
+
+@pytest.mark.gpu
+def test_window_chunk_argument_errors(pkg):
+    rs = np.random.default_rng(32)
+    fea, tg, ws, tf, natm, nr, rows, trows = _window_case(rs, False)
+    ls = [rows.shape[1], 16, tg.shape[1]]
+    W = [None] + [np.zeros((ls[l - 1], ls[l]), np.float32) for l in (1, 2)]
+    b = [None] + [np.zeros(ls[l], np.float32) for l in (1, 2)]
+    g = pkg.BP_GPU(1, 3, ls, 8, 0.1, 0.5, 0.0, W, b)
+    bad = ws.copy(); bad[3] = fea.shape[0] - 2                   # window would run past the last raw frame
+    with pytest.raises(pkg.BPError):
+        g.train_windows(fea, tg, 5, bad, tf)
+    with pytest.raises(pkg.BPError):
+        g.train_windows(fea, tg, 4, ws, tf)                      # context*fea_dim != layersizes[0]
+    badt = tf.copy(); badt[0] = -1
+    with pytest.raises(pkg.BPError):
+        g.CrossValid_windows(fea, tg, 5, ws, badt)
+    with pytest.raises(pkg.BPError):
+        g.train_windows(fea, tg, 5, ws, tf, nat=np.zeros((2, fea.shape[1]), np.float32), nat_row=np.zeros(ws.size, np.int32))
+    g.train_windows(fea, tg, 5, ws, tf)                          # and the handle is still usable
