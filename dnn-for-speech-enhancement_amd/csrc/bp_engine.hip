@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/bp_c_api.h"
@@ -51,6 +52,15 @@ struct bp_handle {
     std::vector<void *> allocs;
     // grow-only device staging of a window chunk (bp_upload_chunk_windows): raw frames, raw targets, NAT rows, tables
     struct Raw { void *p; size_t bytes; } raw[4];
+    // Upload path: host->device copies run on copy_stream so that chunk i+1 is uploaded while chunk i trains.
+    // Stacked chunks alternate between two device buffers (in/targ and in_alt/targ_alt, the second pair allocated
+    // on first use); window chunks go through the raw staging above and are expanded into `in` in stream order.
+    hipStream_t copy_stream;
+    hipEvent_t ev_copy;            // copy_stream: this chunk's H2D copies are done
+    hipEvent_t ev_retired;         // main stream: the buffer pair that is NOT current is no longer read
+    hipEvent_t ev_staging;         // main stream: the raw staging has been expanded
+    bool retired_valid, staging_valid;
+    float *in_alt, *targ_alt;
 };
 
 static uint32_t drop_threshold(float p)
@@ -88,6 +98,10 @@ extern "C" int bp_destroy(bp_handle *h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     for (void *p : h->allocs) (void)hipFree(p);
     for (auto &r : h->raw) if (r.p) (void)hipFree(r.p);
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
+    if (h->ev_retired) (void)hipEventDestroy(h->ev_retired);
+    if (h->ev_staging) (void)hipEventDestroy(h->ev_staging);
     if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -140,6 +154,10 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->stream = h->own_stream;
     HK(hipEventCreate(&h->ev0));
     HK(hipEventCreate(&h->ev1));
+    HK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HK(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
+    HK(hipEventCreateWithFlags(&h->ev_retired, hipEventDisableTiming));
+    HK(hipEventCreateWithFlags(&h->ev_staging, hipEventDisableTiming));
     const int L = h->L;
     const size_t Bp = (size_t)((h->B + 63) & ~63);             // bunch rows rounded up to a whole tile
     const size_t capp = (size_t)h->cap + 64;
@@ -412,13 +430,29 @@ extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, cons
     HIPCHK(hipSetDevice(h->cfg.device));
     const int L = h->L;
     if (n_frames > 0) {
-        HIPCHK(hipMemcpy2DAsync(h->in, (size_t)h->ld[0] * 4, in, (size_t)h->s[0] * 4, (size_t)h->s[0] * 4, n_frames,
-                                hipMemcpyHostToDevice, h->stream));
+        // into the buffer pair that is not current, on the copy stream: the bunches of the previous chunk (still
+        // running on the main stream out of the current pair) overlap this upload
+        if (!h->in_alt) {
+            const size_t capp = (size_t)h->cap + 64;
+            int r;
+            if ((r = dev_alloc(h, &h->in_alt, capp * h->ld[0])) != BP_OK || (r = dev_alloc(h, &h->targ_alt, capp * h->ld[L - 1])) != BP_OK)
+                return r;
+            HIPCHK(hipStreamSynchronize(h->stream));            // (dev_alloc zero-fills on the main stream)
+        }
+        if (h->retired_valid) HIPCHK(hipStreamWaitEvent(h->copy_stream, h->ev_retired, 0));
+        HIPCHK(hipMemcpy2DAsync(h->in_alt, (size_t)h->ld[0] * 4, in, (size_t)h->s[0] * 4, (size_t)h->s[0] * 4, n_frames,
+                                hipMemcpyHostToDevice, h->copy_stream));
         if (targ)
-            HIPCHK(hipMemcpy2DAsync(h->targ, (size_t)h->ld[L - 1] * 4, targ, (size_t)h->s[L - 1] * 4,
-                                    (size_t)h->s[L - 1] * 4, n_frames, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpy2DAsync(h->targ_alt, (size_t)h->ld[L - 1] * 4, targ, (size_t)h->s[L - 1] * 4,
+                                    (size_t)h->s[L - 1] * 4, n_frames, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(hipEventRecord(h->ev_copy, h->copy_stream));
         // the caller may overwrite in/targ as soon as we return (BPtrain.cc:50-53)
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(h->copy_stream));
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
+        HIPCHK(hipEventRecord(h->ev_retired, h->stream));       // everything queued so far read the old pair
+        h->retired_valid = true;
+        std::swap(h->in, h->in_alt);
+        std::swap(h->targ, h->targ_alt);
     }
     h->chunk_frames = n_frames;
     h->mask_lo = h->mask_hi = -1;
@@ -430,7 +464,10 @@ static int raw_reserve(bp_handle *h, int which, size_t bytes)
 {
     bp_handle::Raw &r = h->raw[which];
     if (bytes <= r.bytes) return BP_OK;
-    if (r.p) { HIPCHK(hipStreamSynchronize(h->stream)); (void)hipFree(r.p); r.p = nullptr; r.bytes = 0; }
+    if (r.p) {
+        HIPCHK(hipStreamSynchronize(h->copy_stream)); HIPCHK(hipStreamSynchronize(h->stream));
+        (void)hipFree(r.p); r.p = nullptr; r.bytes = 0;
+    }
     const size_t want = bytes + bytes / 4 + 4096;
     hipError_t e = hipMalloc(&r.p, want);
     if (e != hipSuccess) return fail(BP_ERR_NOMEM, std::string("hipMalloc (window staging): ") + hipGetErrorString(e));
@@ -468,23 +505,33 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
             return r;
         float *d_fea = (float *)h->raw[0].p, *d_tg = (float *)h->raw[1].p, *d_nat = (float *)h->raw[2].p;
         int *d_ws = (int *)h->raw[3].p, *d_tf = d_ws + n, *d_nr = d_tf + n;
-        HIPCHK(hipMemcpyAsync(d_fea, c->fea, fea_b, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(d_ws, c->win_start, idx_b, hipMemcpyHostToDevice, h->stream));
+        // raw frames + tables -> staging on the copy stream (overlaps the previous chunk's bunches); the expansion
+        // into the chunk buffer is queued on the main stream behind them
+        hipStream_t cs = h->copy_stream;
+        if (h->staging_valid) HIPCHK(hipStreamWaitEvent(cs, h->ev_staging, 0));
+        HIPCHK(hipMemcpyAsync(d_fea, c->fea, fea_b, hipMemcpyHostToDevice, cs));
+        HIPCHK(hipMemcpyAsync(d_ws, c->win_start, idx_b, hipMemcpyHostToDevice, cs));
         if (nat) {
-            HIPCHK(hipMemcpyAsync(d_nat, c->nat, nat_b, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(d_nr, c->nat_row, idx_b, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d_nat, c->nat, nat_b, hipMemcpyHostToDevice, cs));
+            HIPCHK(hipMemcpyAsync(d_nr, c->nat_row, idx_b, hipMemcpyHostToDevice, cs));
         }
+        if (with_targ) {
+            HIPCHK(hipMemcpyAsync(d_tg, c->targ_frames, tg_b, hipMemcpyHostToDevice, cs));
+            HIPCHK(hipMemcpyAsync(d_tf, c->targ_frame, idx_b, hipMemcpyHostToDevice, cs));
+        }
+        HIPCHK(hipEventRecord(h->ev_copy, cs));
+        HIPCHK(hipStreamSynchronize(cs));                       // the caller may overwrite its buffers as soon as we return
+        HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
         const int yb = (h->ld[0] + 1023) / 1024 > 0 ? (h->ld[0] + 1023) / 1024 : 1;
         hipLaunchKernelGGL(bp_expand_windows, dim3((unsigned)n, (unsigned)yb), dim3(256), 0, h->stream, h->in, h->ld[0], h->s[0],
                            d_fea, D, ctx * D, nat ? d_nat : (const float *)nullptr, d_ws, nat ? d_nr : (const int *)nullptr, n);
         HIPCHK(hipGetLastError());
         if (with_targ) {
-            HIPCHK(hipMemcpyAsync(d_tg, c->targ_frames, tg_b, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(d_tf, c->targ_frame, idx_b, hipMemcpyHostToDevice, h->stream));
             hipLaunchKernelGGL(bp_gather_rows, dim3((unsigned)n, 1), dim3(256), 0, h->stream, h->targ, h->ld[L - 1], sL, d_tg, d_tf, n);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipStreamSynchronize(h->stream));       // the caller may overwrite its buffers as soon as we return
+        HIPCHK(hipEventRecord(h->ev_staging, h->stream));
+        h->staging_valid = true;
     }
     h->chunk_frames = n;
     h->mask_lo = h->mask_hi = -1;

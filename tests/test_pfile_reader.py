@@ -15,7 +15,7 @@ HOST = os.path.join(ROOT, "dnn-for-speech-enhancement_amd", "csrc", "host")
 @pytest.fixture(scope="module")
 def dump_exe(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("bin") / "reader_dump")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", os.path.join(ROOT, "tests", "cpp", "reader_dump.cc"),
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-pthread", os.path.join(ROOT, "tests", "cpp", "reader_dump.cc"),
                            os.path.join(HOST, "pfile_reader.cpp"), os.path.join(HOST, "wts_io.cpp"), "-o", exe])
     return exe
 
