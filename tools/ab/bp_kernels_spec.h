@@ -1,3 +1,6 @@
+// EXPERIMENT RECORD (not built): bp_kernels.h with a wave-specialised mode (GemmKernel<..., SPEC=true>, bp_gemm_spec: 4 multiplying +
+// 4 staging waves per workgroup).  Measured 20 % SLOWER than the fused pipeline on the 256x2048x2048 GEMMs (29.5 vs 24.3 us).
+
 // bp_kernels.h -- CDNA4 (gfx950) kernels of the frame-wise DNN step.
 //
 // One LDS-staged fp32 MFMA GEMM template (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered
@@ -564,7 +567,10 @@ struct GemmCfg {
 // (static register indices).  Why: s_waitcnt vmcnt is in-order, so when all of it is issued up front
 // the very first operand-tile wait also waits for that whole burst (67 MB chip-wide for a 2048x2048
 // layer) -- the prologue of wgrad then takes 4.2 us instead of 1.3 us (in-kernel timestamps).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0>
+// SPEC: wave-specialised variant, 512 threads: waves 0-3 only multiply (ds_read + MFMA), waves 4-7 only stage
+// (global_load -> ds_write) with the same per-thread tile mapping; one barrier per k-tile joins them.  A stalled
+// vmcnt wait then blocks a staging wave, not the MFMA stream, and a tile has two iterations to land instead of one.
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0, bool SPEC = false>
 struct GemmKernel {
     using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
     static constexpr bool STATIC_K = NT_S > 0 && PF == 1 && EPI == EPI_WGRAD_UPDATE && Cfg::KS == 1 && NT_S <= 32 && NT_S >= 4;
@@ -582,7 +588,10 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
                                            int block_y, float *smem)
 {
     using Regs = typename Cfg::Regs;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform => SGPR row bases
+    static_assert(!SPEC || (PF == 1 && !STATIC_K && !BIASG), "wave specialisation: plain 2-stage pipeline, no bias reduction");
+    const int tid = SPEC ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform => SGPR row bases
+    const bool stager = SPEC && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) != 0;   // waves 4-7 of a SPEC workgroup
     const int ks = wave / (WM * WN), wq = wave % (WM * WN), wm = wq / WN, wn = wq % WN;
     GemmArgs g = g_in;
     EpiArgs e = e_in;
@@ -644,6 +653,8 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     const int mb0 = m0 + wm * TM * 32, nb0 = n0 + wn * TN * 32;
     if constexpr (STATIC_K) {
         // fetched piecewise inside the unrolled k-loop below
+    } else if (stager) {
+        // staging waves have no epilogue
     } else if constexpr (KS == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -675,11 +686,20 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
 #define STEP(ST, LD, buf, RS, RL, TL)                                                                      \
     Cfg::template step<ST, LD>(AS(buf), BS(buf), accs, ks, a_off, b_off, kh, RS, AS((buf) ^ 1), BS((buf) ^ 1),    \
                                RL, PA(TL), PB(TL), offs, tid, bsum)
+// staging-only counterpart of STEP for the staging waves of a SPEC workgroup: issue the loads of tile TL first, then
+// move image RS (loaded one iteration ago) into the stage that is not being multiplied
+#define STAGE_ONLY(ST, LD, buf, RS, RL, TL)                                                                 \
+    do {                                                                                                   \
+        if constexpr (LD) Cfg::load(RL, PA(TL), PB(TL), offs);                                             \
+        if constexpr (ST) Cfg::store(RS, AS((buf) ^ 1), BS((buf) ^ 1), tid, bsum);                         \
+    } while (0)
     Regs r0, r1, r2;
-    Cfg::load(r0, PA(0), PB(0), offs);
-    Cfg::store(r0, AS(0), BS(0), tid, bsum);
-    Cfg::load(r1, PA(1), PB(1), offs);
-    if constexpr (PF >= 2) Cfg::load(r2, PA(2), PB(2), offs);
+    if (!SPEC || stager) {
+        Cfg::load(r0, PA(0), PB(0), offs);
+        Cfg::store(r0, AS(0), BS(0), tid, bsum);
+        Cfg::load(r1, PA(1), PB(1), offs);
+        if constexpr (PF >= 2) Cfg::load(r2, PA(2), PB(2), offs);
+    }
     __syncthreads();
     TRACE(1);
     // Invariant at the top of iteration t: LDS stage t&1 holds tile t; tile t+1 (and t+2 when
@@ -711,6 +731,33 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
         SBODY(24) SBODY(25) SBODY(26) SBODY(27) SBODY(28) SBODY(29) SBODY(30) SBODY(31)
 #undef SBODY
         epilogue_fetch_pieces<EPI, TM, TN, NT_S * PER, NPRE>(e, mb0, nb0, lane, pre);   // (none left when PER covers all)
+    } else
+    if constexpr (SPEC) {
+        if (stager) {
+            for (; t + 3 <= nt; t += 2) {
+                STAGE_ONLY(true, true, 0, r1, r0, t + 2);
+                __syncthreads();
+                STAGE_ONLY(true, true, 1, r0, r1, t + 3);
+                __syncthreads();
+            }
+            if (nt - t == 2) {
+                STAGE_ONLY(true, false, 0, r1, r0, 0);
+                __syncthreads();
+            }
+            __syncthreads();               // (the multiplying waves' last tile)
+            return;                        // staging waves are done; later barriers count the remaining waves only
+        }
+        for (; t + 3 <= nt; t += 2) {
+            STEP(false, false, 0, r1, r0, 0);
+            __syncthreads();
+            STEP(false, false, 1, r0, r1, 0);
+            __syncthreads();
+        }
+        if (nt - t == 2) {
+            STEP(false, false, 0, r1, r0, 0);
+            __syncthreads();
+            buf = 1;
+        }
     } else
     if constexpr (PF == 1) {
         // tile t+1 in r1 (even t) / r0 (odd t)
@@ -759,6 +806,7 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
 #undef AS
 #undef BS
 #undef STEP
+#undef STAGE_ONLY
     // fold the independent accumulator chains
     f32x16 (&acc)[TM][TN] = accs[0];
     if constexpr (NCH == 2) {
@@ -839,6 +887,15 @@ template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI,
 __global__ __launch_bounds__(256, (GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>::MIN_WG)) void bp_gemm(const GemmArgs g, const EpiArgs e)
 {
     using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>;
+    __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
+    K::run(g, e, blockIdx.x, gridDim.x, blockIdx.y, smem);
+}
+
+// wave-specialised launch shape (GemmKernel<..., SPEC = true>): 512 threads, one tile per workgroup
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int TAG = 0>
+__global__ __launch_bounds__(512, 1) void bp_gemm_spec(const GemmArgs g, const EpiArgs e)
+{
+    using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, 1, 0, true>;
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     K::run(g, e, blockIdx.x, gridDim.x, blockIdx.y, smem);
 }

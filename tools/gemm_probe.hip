@@ -80,6 +80,11 @@ int main(int argc, char **argv)
 #define FWD(BM, BN, BK, WM, WN, PF) vs.push_back({"fwd  " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); go<BM, BN, BK, WM, WN, true, false, EPI_FWD_HIDDEN, PF>(s, g, e, B, H, 0); }, fl})
 #define DGR(BM, BN, BK, WM, WN, PF) vs.push_back({"dgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF, [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); go<BM, BN, BK, WM, WN, true, true, EPI_DGRAD, PF>(s, g, e, B, H, 0); }, fl})
 #define WGR(BM, BN, BK, WM, WN, PF, DYN) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " pf" #PF " grid" #DYN, [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, PF>(s, g, e, H, H, DYN); }, 2.0 * H * H * (double)KW})
+    // split-K over 2 (4) workgroup rows: 512 (1024) workgroups = 2 (4) per CU running out of phase; partial sums
+    // stored plainly (EPI_PARTIAL).  Compare with "fwdP1" = the same plain-store kernel without the split.
+#define FWDSK(NS) vs.push_back({"fwdSK" #NS " 32x64x64 w1x2 partial", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.K = H / NS; g.k_split = H / NS; g.slab_stride = (size_t)B * LDMAX; e.C = dX; \
+        g.tiles_m = B / 32; g.tiles_n = H / 64; hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_PARTIAL, 1>), dim3(g.tiles_m * g.tiles_n, NS), dim3(256), 0, s, g, e); }, fl})
+    FWDSK(1); FWDSK(2); FWDSK(4);
     // same kernel, every k-row of W aliased to row 0 (ldb = 0): operands always hit L2 -> isolates HBM/MALL latency
     vs.push_back({"fwdL2 32x64x64 w1x2 pf1 (ldb=0)", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.ldb = 0; go<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>(s, g, e, B, H, 0); }, fl});
     FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 128, 1, 2, 1); FWD(64, 32, 128, 2, 1, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);

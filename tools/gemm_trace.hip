@@ -81,6 +81,14 @@ int main(int argc, char **argv)
             }
             printf("  k-tile durations: t0 %.2f t1 %.2f t2 %.2f t3 %.2f, t4..7 avg %.2f us\n", d[0], d[1], d[2], d[3], d[4]);
         }
+        if (!wg64) {
+            double mhz = 0; int cnt = 0;
+            for (int b = 0; b < NWG; ++b) {
+                const unsigned long long *q = &h[((size_t)l * NWG + b) * 8];
+                if (q[3] > q[0] && q[7] > q[6]) { mhz += (double)(q[7] - q[6]) / (double)(q[3] - q[0]) * 100.0; ++cnt; }
+            }
+            printf("  shader clock during the kernel (clock64 / wall_clock64): %.0f MHz\n", cnt ? mhz / cnt : 0.0);
+        }
         printf("launch %d (%s K=%d): entry [%.2f..%.2f] prologue_done [%.2f..%.2f] loop_done [%.2f..%.2f] end [%.2f..%.2f] us | per-WG avg: prologue %.2f loop %.2f epilogue %.2f\n",
                l, wgrad ? "wgrad 128x64x16" : "fwd 32x64x64", K, mn[0], mx[0], mn[1], mx[1], mn[2], mx[2], mn[3], mx[3], dur[0], dur[1], dur[2]);
     }
