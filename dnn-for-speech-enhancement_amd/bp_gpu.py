@@ -57,6 +57,7 @@ class BPConfig(C.Structure):
         ("dropoutflag", C.c_int), ("visible_omit", C.c_float), ("hid_omit", C.c_float),
         ("activation", C.c_int), ("momentum_rule", C.c_int), ("seed", C.c_uint64), ("device", C.c_int),
         ("global_bunchsize", C.c_int), ("rank_frame_offset", C.c_int), ("max_chunk_frames", C.c_int),
+        ("compute_dtype", C.c_int),
     ]
 
 
@@ -133,7 +134,7 @@ class BP_GPU(object):
 
     def __init__(self, gpu_used, numlayers, layersizes, bunchsize, lrate, momentum, weightcost, weights, bias,
                  dropoutflag=0, visible_omit=0.0, hid_omit=0.0, activation=0, momentum_rule=0, seed=0, device=0,
-                 global_bunchsize=0, rank_frame_offset=0, max_chunk_frames=0, strict_exit=False):
+                 global_bunchsize=0, rank_frame_offset=0, max_chunk_frames=0, strict_exit=False, compute_dtype=0):
         self._h = None
         self._strict = strict_exit
         self._lib = load_library()
@@ -151,6 +152,7 @@ class BP_GPU(object):
         cfg.activation, cfg.momentum_rule, cfg.seed, cfg.device = int(activation), int(momentum_rule), int(seed), int(device)
         cfg.global_bunchsize, cfg.rank_frame_offset = int(global_bunchsize), int(rank_frame_offset)
         cfg.max_chunk_frames = int(max_chunk_frames)
+        cfg.compute_dtype = int(compute_dtype)          # 0 fp32 (reference) | 1 bf16 operands, fp32 accumulate / master weights
         self._cfg = cfg
         if len(self.layersizes) != self.numlayers or self.numlayers < 2 or self.numlayers > MAXLAYER - 1:
             self._fail("numlayers must be in 2..%d and match layersizes" % (MAXLAYER - 1))

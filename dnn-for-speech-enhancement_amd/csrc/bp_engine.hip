@@ -18,6 +18,7 @@
 
 #include "../../include/bp_c_api.h"
 #include "bp_kernels.h"
+#include "bp_bf16.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -61,6 +62,12 @@ struct bp_handle {
     hipEvent_t ev_staging;         // main stream: the raw staging has been expanded
     bool retired_valid, staging_valid;
     float *in_alt, *targ_alt;
+    // compute_dtype == 1 (bp_bf16.h): bf16 copies, each in both orientations
+    bool bf;
+    int Bp;                                                  // bunch rows rounded up to 64
+    bf16_t *Wb[BP_MAXLAYER], *WbT[BP_MAXLAYER];              // [prev][cur], [cur][prev]
+    bf16_t *yb[BP_MAXLAYER], *ybT[BP_MAXLAYER];              // [Bp][ld_l], [ld_l][Bp]   (l = 0: the input bunch)
+    bf16_t *dxb[BP_MAXLAYER], *dxbT[BP_MAXLAYER];
 };
 
 static uint32_t drop_threshold(float p)
@@ -72,7 +79,7 @@ static uint32_t drop_threshold(float p)
 }
 
 extern "C" const char *bp_last_error(void) { return g_err.c_str(); }
-extern "C" int bp_abi_version(void) { return 1; }
+extern "C" int bp_abi_version(void) { return 2; }   // 2: bp_config.compute_dtype, bp_window_chunk
 extern "C" const char *bp_build_target(void) { return "gfx950"; }
 
 // Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM
@@ -110,6 +117,9 @@ extern "C" int bp_destroy(bp_handle *h)
     return BP_OK;
 }
 
+static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs);
+static hipError_t bf_shadow(bp_handle *h, int l);
+
 extern "C" int bp_create(const bp_config *cfg, const float *const *weights, const float *const *bias,
                          bp_handle **out)
 {
@@ -119,6 +129,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
         return fail(BP_ERR_ARG, "bp_create: numlayers must be in 2..9");
     if (cfg->bunchsize < 1) return fail(BP_ERR_ARG, "bp_create: bunchsize must be >= 1");
     if (cfg->gpu_used < 1) return fail(BP_ERR_ARG, "bp_create: gpu_used must be >= 1");  // BP_GPU.cu:20-24
+    if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) return fail(BP_ERR_ARG, "bp_create: compute_dtype must be 0 (fp32) or 1 (bf16)");
     for (int l = 0; l < cfg->numlayers; ++l)
         if (cfg->layersizes[l] < 1) return fail(BP_ERR_ARG, "bp_create: layer size must be >= 1");
     int ndev = 0;
@@ -191,6 +202,20 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
         HK(hipMemcpy2DAsync(h->W[l], (size_t)h->ld[l] * 4, weights[l], (size_t)h->s[l] * 4, (size_t)h->s[l] * 4,
                             h->s[l - 1], hipMemcpyHostToDevice, h->stream));
         HK(hipMemcpyAsync(h->b[l], bias[l], (size_t)h->s[l] * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    h->bf = cfg->compute_dtype == 1;
+    h->Bp = (int)Bp;
+    if (h->bf) {
+        for (int l = 0; l < L; ++l) {
+            const size_t act = Bp * (size_t)h->ld[l];
+            if (l < L - 1) { CK(bf_alloc(h, &h->yb[l], act)); CK(bf_alloc(h, &h->ybT[l], act)); }
+            if (l >= 1) {
+                CK(bf_alloc(h, &h->dxb[l], act)); CK(bf_alloc(h, &h->dxbT[l], act));
+                const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
+                CK(bf_alloc(h, &h->Wb[l], nw)); CK(bf_alloc(h, &h->WbT[l], nw));
+                HK(bf_shadow(h, l));
+            }
+        }
     }
     HK(hipStreamSynchronize(h->stream));
 #undef CK
@@ -387,6 +412,100 @@ static hipError_t mask_range(bp_handle *h, int first, int n)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ compute_dtype == 1 (bp_bf16.h)
+static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs)
+{
+    float *q = nullptr;
+    const int r = dev_alloc(h, &q, (n_halfs + 1) / 2);       // zero-filled, with slack
+    *p = (bf16_t *)q;
+    return r;
+}
+static hipError_t bf_convert(bp_handle *h, const float *src, int lds, int rows, int cols, bf16_t *out, int ldo, bf16_t *outT,
+                             int ldt, int rows_pad, int cols_pad)
+{
+    hipLaunchKernelGGL(bp_to_bf16_both, dim3((cols_pad + 31) / 32, (rows_pad + 31) / 32), dim3(32, 8), 0, h->stream, src, lds,
+                       rows, cols, out, ldo, outT, ldt, rows_pad, cols_pad);
+    return hipGetLastError();
+}
+// fp32 master weights of layer l -> bf16 shadow in both orientations (creation, data-parallel update)
+static hipError_t bf_shadow(bp_handle *h, int l)
+{
+    const int prev = h->ld[l - 1], cur = h->ld[l];
+    return bf_convert(h, h->W[l], cur, prev, cur, h->Wb[l], cur, h->WbT[l], prev, prev, cur);
+}
+template <int EPI>
+static hipError_t bf_launch(bp_handle *h, const BfGemmArgs &g, const BfEpiArgs &e)
+{
+    hipLaunchKernelGGL((bp_gemm_bf16<EPI>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
+    return hipGetLastError();
+}
+// forward of weight layer l on M frames (bf16 operands); train: hidden outputs get the hid_omit mask, the output
+// layer emits dEdX_L; out (fp32, [M][ld_L]) optional
+static hipError_t bf_fwd(bp_handle *h, int l, int M, const float *targ, float *out, bool train, float alpha)
+{
+    const int L = h->L, prev = h->ld[l - 1], cur = h->ld[l];
+    BfGemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = h->yb[l - 1]; g.lda = prev; g.B = h->WbT[l]; g.ldb = prev; g.K = prev; g.tiles_m = h->Bp / 64; g.tiles_n = cur / 64;
+    BfEpiArgs e; memset(&e, 0, sizeof(e));
+    e.m_limit = M; e.n_limit = cur; e.n_true = h->s[l]; e.bias = h->b[l]; e.alpha = alpha; e.act = h->cfg.activation;
+    e.ldc = cur; e.ldct = h->Bp;
+    if (l != L - 1) {
+        e.C = h->yb[l]; e.CT = h->ybT[l];
+        e.drop_thresh = train ? h->th_hid : 0u;
+        e.seed_lo = (uint32_t)h->cfg.seed; e.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+        e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
+        return bf_launch<BEPI_FWD_HIDDEN>(h, g, e);
+    }
+    e.scale = 2.0f / (float)h->Bg;
+    e.targ = targ; e.ldt = cur; e.out = out; e.ldo = cur;
+    if (train) { e.C = h->dxb[l]; e.CT = h->dxbT[l]; }
+    return bf_launch<BEPI_FWD_OUT>(h, g, e);
+}
+static hipError_t bf_input(bp_handle *h, const float *x0, int M)
+{
+    return bf_convert(h, x0, h->ld[0], M, h->ld[0], h->yb[0], h->ld[0], h->ybT[0], h->Bp, h->Bp, h->ld[0]);
+}
+static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool fused)
+{
+    const int L = h->L, B = h->B;
+    hipError_t er;
+#define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
+    CKE(bf_input(h, x0, B));
+    for (int l = 1; l < L; ++l) CKE(bf_fwd(h, l, B, tg, nullptr, true, 1.0f));
+    for (int l = L - 1; l >= 2; --l) {               // dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T), pre-update weights
+        const int prev = h->ld[l - 1], cur = h->ld[l];
+        BfGemmArgs g; memset(&g, 0, sizeof(g));
+        g.A = h->dxb[l]; g.lda = cur; g.B = h->Wb[l]; g.ldb = cur; g.K = cur; g.tiles_m = h->Bp / 64; g.tiles_n = prev / 64;
+        BfEpiArgs e; memset(&e, 0, sizeof(e));
+        e.m_limit = B; e.n_limit = prev; e.n_true = h->s[l - 1]; e.act = h->cfg.activation;
+        e.C = h->dxb[l - 1]; e.ldc = prev; e.CT = h->dxbT[l - 1]; e.ldct = h->Bp; e.yprev = h->yb[l - 1]; e.ldy = prev;
+        CKE(bf_launch<BEPI_DGRAD>(h, g, e));
+    }
+    for (int l = 1; l < L; ++l) {                    // G_l = y_{l-1}^T . dEdX_l  (+ update / store), bias gradient
+        const int prev = h->ld[l - 1], cur = h->ld[l];
+        BfGemmArgs g; memset(&g, 0, sizeof(g));
+        g.A = h->ybT[l - 1]; g.lda = h->Bp; g.B = h->dxbT[l]; g.ldb = h->Bp; g.K = h->Bp; g.tiles_m = prev / 64; g.tiles_n = cur / 64;
+        BfEpiArgs e; memset(&e, 0, sizeof(e));
+        e.m_limit = prev; e.n_limit = cur; e.n_true = h->s[l]; e.ldw = cur;
+        const float m = h->cfg.momentum, lr = h->cfg.lrate;
+        const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
+        if (fused) {
+            e.W = h->W[l]; e.D = h->dW[l]; e.mom = m; e.c1 = c1; e.wc = h->cfg.weightcost; e.ndiv = (float)h->Bg;
+            e.C = h->Wb[l]; e.ldc = cur; e.CT = h->WbT[l]; e.ldct = prev;
+            CKE(bf_launch<BEPI_WGRAD_UPDATE>(h, g, e));
+        } else {
+            e.W = h->grad + h->g_off[l];
+            CKE(bf_launch<BEPI_WGRAD_STORE>(h, g, e));
+        }
+        hipLaunchKernelGGL(bp_bias_bf16, dim3((h->s[l] + 255) / 256), dim3(256), 0, h->stream, h->dxb[l], cur, B, h->s[l],
+                           h->b[l], h->db[l], fused ? (float *)nullptr : h->grad + h->g_off[l] + (size_t)prev * cur, m, c1,
+                           (float)h->Bg);
+        CKE(hipGetLastError());
+    }
+#undef CKE
+    return hipSuccess;
+}
+
 // One bunch starting at chunk frame `first`: forward + backward.  fused: momentum update inside
 // the wgrad epilogues (train_bunch_single); else gradients to the flat buffer.  Everything is
 // enqueued on one stream in the reference's order (BP_GPU.cu:518-671); every dgrad of the step
@@ -405,6 +524,7 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
         x0 = h->in_drop + (size_t)first * h->ld[0];
     }
     const float *tg = h->targ + (size_t)first * h->ld[L - 1];
+    if (h->bf) return bf_bunch(h, x0, tg, fused);
     for (int l = 1; l < L; ++l)
         CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
     // Every dgrad of the step reads pre-update weights (BP_GPU.cu:636 runs before :643-652 of the same
@@ -630,6 +750,7 @@ static hipError_t dp_input(bp_handle *h, int first, const float **x0)
 extern "C" int bp_dp_forward_layer(bp_handle *h, int first_frame, int layer)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_forward_layer: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_forward_layer: layer out of range");
     if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_dp_forward_layer: bunch outside the resident chunk");
@@ -657,6 +778,7 @@ extern "C" int bp_dp_forward(bp_handle *h, int first_frame)
 extern "C" int bp_dp_dgrads(bp_handle *h)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_dgrads: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (h->dp_next_layer != h->L - 1) return fail(BP_ERR_STATE, "bp_dp_dgrads: run the forward of a bunch first");
     HIPCHK(hipSetDevice(h->cfg.device));
     for (int l = h->L - 1; l >= 2; --l) HIPCHK(launch_dgrad(h, h->stream, l, h->B));
@@ -667,6 +789,7 @@ extern "C" int bp_dp_dgrads(bp_handle *h)
 extern "C" int bp_dp_wgrad_layer(bp_handle *h, int layer)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_wgrad_layer: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_wgrad_layer: layer out of range");
     if (h->dp_next_layer != -1) return fail(BP_ERR_STATE, "bp_dp_wgrad_layer: call bp_dp_dgrads first");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -679,6 +802,7 @@ extern "C" int bp_dp_wgrad_layer(bp_handle *h, int layer)
 extern "C" int bp_dp_backward_layer(bp_handle *h, int layer)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_backward_layer: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_backward_layer: layer out of range");
     if (layer != h->dp_next_layer)
         return fail(BP_ERR_STATE, "bp_dp_backward_layer: call bp_dp_forward first, then layers numlayers-1 ... 1 in order");
@@ -693,6 +817,14 @@ extern "C" int bp_dp_backward_layer(bp_handle *h, int layer)
 
 extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
 {
+    if (h && h->bf) {            // bf16 operands: whole bunch at once, gradients (fp32) to the flat buffer
+        if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
+            return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
+        HIPCHK(hipSetDevice(h->cfg.device));
+        if (!h->grad) { int r0 = dev_alloc(h, &h->grad, h->grad_floats); if (r0 != BP_OK) return r0; }
+        HIPCHK(bunch(h, first_frame, false));
+        return BP_OK;
+    }
     int r = bp_dp_forward(h, first_frame);
     for (int l = h ? h->L - 1 : 0; r == BP_OK && l >= 1; --l) r = bp_dp_backward_layer(h, l);
     return r;
@@ -766,6 +898,7 @@ extern "C" int bp_apply_update_layer(bp_handle *h, int l)
     hipLaunchKernelGGL(bp_update_flat, dim3(2048), dim3(256), 0, h->stream, h->W[l], h->dW[l], g, nw, h->b[l], h->db[l],
                        g + nw, h->ld[l], m, c1, h->cfg.weightcost, (float)h->Bg);
     HIPCHK(hipGetLastError());
+    if (h->bf) HIPCHK(bf_shadow(h, l));          // refresh the bf16 copies the next forward / dgrad read
     return BP_OK;
 }
 
@@ -791,9 +924,11 @@ static int forward_bunch(bp_handle *h, int first, int fb)
 {
     const int L = h->L;
     const float vis_keep = 1.0f - h->cfg.visible_omit, hid_keep = 1.0f - h->cfg.hid_omit;   // BP_GPU.cu:703-704
+    if (h->bf) HIPCHK(bf_input(h, h->in + (size_t)first * h->ld[0], fb));
     for (int l = 1; l < L; ++l) {
         float alpha = 1.0f;
         if (h->cfg.dropoutflag == 1) alpha = (l == 1) ? vis_keep : hid_keep;
+        if (h->bf) { HIPCHK(bf_fwd(h, l, fb, nullptr, h->out_dev, false, alpha)); continue; }
         const float *yp = (l == 1) ? h->in + (size_t)first * h->ld[0] : h->y[l - 1];
         HIPCHK(launch_fwd(h, h->stream, l, fb, yp, nullptr, h->out_dev, false, alpha));
     }
@@ -891,6 +1026,7 @@ extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
     if (!h || !avg_ms || iters < 1) return fail(BP_ERR_ARG, "bp_time_kernel: bad argument");
     if (h->L < 4 && (which == 0 || which == 1 || which == 2))
         return fail(BP_ERR_ARG, "bp_time_kernel: needs a hidden->hidden layer (numlayers >= 4)");
+    if (h->bf) return fail(BP_ERR_STATE, "bp_time_kernel: fp32 kernels only");
     if (h->chunk_frames < h->B) return fail(BP_ERR_STATE, "bp_time_kernel: no resident chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int L = h->L, B = h->B;

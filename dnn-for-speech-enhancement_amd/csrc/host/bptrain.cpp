@@ -6,7 +6,7 @@
 // (finetune_DNN_speech_enhancement_dropout_NAT.pl) can call this binary unchanged.
 //
 // Extra optional keys (defaults = live reference behaviour): activation=relu|sigmoid,
-// momentum_rule=live|classic, seed=<u64> (dropout stream), device=<ordinal>;
+// momentum_rule=live|classic, seed=<u64> (dropout stream), device=<ordinal>, compute=fp32|bf16;
 // stack=device|host (default device: raw frames + index tables go to the GPU, which builds the context
 // windows -- 11x less host work and upload, identical samples; host = the reference's Readchunk layout),
 // prefetch=1|0 (default 1: the next chunk is read while the current one is uploaded / trained).
@@ -120,6 +120,7 @@ int main(int argc, char **argv)
         else if (k == "momentum_rule") setenv("BP_MOMENTUM_RULE", v.c_str(), 1);
         else if (k == "seed") setenv("BP_SEED", v.c_str(), 1);
         else if (k == "device") setenv("BP_DEVICE", v.c_str(), 1);
+        else if (k == "compute") setenv("BP_COMPUTE_DTYPE", v.c_str(), 1);      // fp32 (default) | bf16
         else if (k == "stack") P.stack_on_device = (v != "host");
         else if (k == "prefetch") P.prefetch = atoi(v.c_str()) != 0;
         // unknown names are silently ignored, as in the reference (e.g. the .pl passes numlayers=)

@@ -18,7 +18,7 @@
  *   - train_windows / CrossValid_windows are additions (on-device frame stacking).
  *   - optional behaviour switches the reference has only as source edits can be set through
  *     environment variables before construction: BP_ACTIVATION=sigmoid|relu,
- *     BP_MOMENTUM_RULE=classic|live, BP_SEED=<u64>, BP_DEVICE=<ordinal>.
+ *     BP_MOMENTUM_RULE=classic|live, BP_SEED=<u64>, BP_DEVICE=<ordinal>, BP_COMPUTE_DTYPE=fp32|bf16.
  */
 #ifndef BP_GPU_SHIM_H
 #define BP_GPU_SHIM_H
@@ -61,6 +61,7 @@ public:
         if ((e = getenv("BP_MOMENTUM_RULE")) != 0) cfg.momentum_rule = strcmp(e, "classic") == 0 ? 1 : 0;
         if ((e = getenv("BP_SEED")) != 0) cfg.seed = strtoull(e, 0, 10);
         if ((e = getenv("BP_DEVICE")) != 0) cfg.device = atoi(e);
+        if ((e = getenv("BP_COMPUTE_DTYPE")) != 0) cfg.compute_dtype = strcmp(e, "bf16") == 0 ? 1 : 0;
         check(bp_create(&cfg, weights, bias, &handle_));
         printf("Created net with %d layers, bunchsize %d.\n", numlayers, bunchsize);   /* BP_GPU.cu:196 */
     }

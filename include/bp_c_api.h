@@ -63,6 +63,13 @@ typedef struct bp_config {
     int   rank_frame_offset;        /* data parallel: index of this rank's first frame inside
                                        the global bunch (keys the dropout stream)               */
     int   max_chunk_frames;         /* capacity of the resident chunk cache; 0 = BP_MAXCACHEFRAME */
+    int   compute_dtype;            /* 0 = fp32 everywhere (the reference).  1 = bf16 GEMM operands
+                                       (activations, errors, a shadow copy of the weights) with fp32
+                                       accumulation, fp32 master weights / momentum / update
+                                       (BASELINE.json configs[4]); parity tolerance 2e-2 instead of
+                                       1e-4.  Supported calls in this mode: train / cv / forward /
+                                       bp_train_resident, bp_grads_resident + bp_apply_update,
+                                       weights and deltas download                               */
 } bp_config;
 
 typedef struct bp_handle bp_handle;

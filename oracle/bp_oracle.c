@@ -54,7 +54,30 @@ typedef struct {
     int   momentum_rule;           /* 0 = live (1-m) rule, 1 = classic (.bak)              */
     int   acc_double;              /* 0 = fp32 accumulation, 1 = fp64 accumulation         */
     uint64_t seed;                 /* Philox key for generated dropout masks               */
+    int   compute_dtype;           /* 0 = fp32 (the reference).  1 = bf16 GEMM operands: weights (a
+                                      rounded copy), the masked input, every stored activation and
+                                      every back-propagated error are rounded to bf16 (nearest even)
+                                      where the HIP path stores them as bf16; accumulation, bias,
+                                      loss, master weights and the update stay fp32
+                                      (BASELINE.json configs[4]; bp_bf16.h)                        */
 } oracle_cfg;
+
+/* bf16 storage rounding (round to nearest even), value returned as float */
+static inline float bf16_round(float f)
+{
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return f;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    u &= 0xFFFF0000u;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static float *bf16_copy(const float *src, size_t n)
+{
+    float *d = (float *)malloc(sizeof(float) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) d[i] = bf16_round(src[i]);
+    return d;
+}
 
 /* ------------------------------------------------------------------ Philox4x32-10 */
 static inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
@@ -253,20 +276,25 @@ void oracle_forward(const oracle_cfg *cfg, float *const *weights, float *const *
     for (int l = 0; l < L; ++l) if (cfg->layersizes[l] > maxw) maxw = cfg->layersizes[l];
     float *a = (float *)malloc(sizeof(float) * (size_t)B * maxw);
     float *b = (float *)malloc(sizeof(float) * (size_t)B * maxw);
-    const float *y = in;
+    const int bf = cfg->compute_dtype == 1;
+    float *inb = bf ? bf16_copy(in, (size_t)B * cfg->layersizes[0]) : NULL;
+    const float *y = bf ? inb : in;
     for (int l = 1; l < L; ++l) {
         const int prev = cfg->layersizes[l - 1], cur = cfg->layersizes[l];
         float keep = 1.0f;
         if (cfg->dropoutflag == 1) keep = (l == 1) ? 1.0f - cfg->visible_omit : 1.0f - cfg->hid_omit;
         float *x = (l == L - 1) ? out : ((l & 1) ? a : b);
-        affine(B, prev, cur, y, weights[l], bias[l], keep, cfg->acc_double, x);
+        float *wb = bf ? bf16_copy(weights[l], (size_t)prev * cur) : NULL;
+        affine(B, prev, cur, y, bf ? wb : weights[l], bias[l], keep, cfg->acc_double, x);
+        free(wb);
         if (l != L - 1) {
             const size_t n = (size_t)B * cur;
             for (size_t i = 0; i < n; ++i) x[i] = act_fwd(cfg->activation, x[i]);
+            if (bf) for (size_t i = 0; i < n; ++i) x[i] = bf16_round(x[i]);
         }
         y = x;
     }
-    free(a); free(b);
+    free(a); free(b); free(inb);
 }
 
 /* CrossValid (BP_GPU.cu:408-479): bunch loop (partial bunch processed), squared error summed
@@ -305,8 +333,12 @@ void oracle_grads(const oracle_cfg *cfg, float *const *weights, float *const *bi
                   float *const *grads_w, float *const *grads_b, float *acts, float *out)
 {
     const int L = cfg->numlayers;
+    const int bf = cfg->compute_dtype == 1;
     float *own_acts = NULL;
     if (!acts) acts = own_acts = (float *)malloc(sizeof(float) * oracle_act_floats(cfg, B));
+    float *wb[BP_MAXLAYER] = {0};              /* bf16 mode: rounded copies of the (pre-update) weights */
+    float *inb = NULL;                         /* bf16 mode: rounded copy of the masked input bunch     */
+    if (bf) for (int l = 1; l < L; ++l) wb[l] = bf16_copy(weights[l], (size_t)cfg->layersizes[l - 1] * cfg->layersizes[l]);
     /* ---- forward, BP_GPU.cu:518-585 */
     for (int l = 1; l < L; ++l) {
         const int prev = cfg->layersizes[l - 1], cur = cfg->layersizes[l];
@@ -316,11 +348,13 @@ void oracle_grads(const oracle_cfg *cfg, float *const *weights, float *const *bi
             const size_t n = (size_t)B * prev;
             for (size_t i = 0; i < n; ++i) if (mk[i]) yprev[i] = 0.0f;  /* kernDropout */
         }
+        if (bf && l == 1) { inb = bf16_copy(in, (size_t)B * prev); yprev = inb; }
         float *x = acts + act_offset(cfg, l, B);
-        affine(B, prev, cur, yprev, weights[l], bias[l], 1.0f, cfg->acc_double, x);
+        affine(B, prev, cur, yprev, bf ? wb[l] : weights[l], bias[l], 1.0f, cfg->acc_double, x);
         if (l != L - 1) {
             const size_t n = (size_t)B * cur;
             for (size_t i = 0; i < n; ++i) x[i] = act_fwd(cfg->activation, x[i]);
+            if (bf) for (size_t i = 0; i < n; ++i) x[i] = bf16_round(x[i]);   /* stored as bf16 (zeros of the next mask stay zeros) */
         }
     }
     const int sL = cfg->layersizes[L - 1];
@@ -343,11 +377,13 @@ void oracle_grads(const oracle_cfg *cfg, float *const *weights, float *const *bi
             for (size_t i = 0; i < n; ++i)
                 dedx[i] = act_bwd(cfg->activation, y[i]) * dedy[i]; /* kernDsigmoid*kernVecMul */
         }
-        if (l != 1) dgrad(B, prev, cur, dedx, weights[l], cfg->acc_double, dedy);
-        const float *yprev = (l == 1) ? in : acts + act_offset(cfg, l - 1, B);
+        if (bf) for (size_t i = 0; i < n; ++i) dedx[i] = bf16_round(dedx[i]);
+        if (l != 1) dgrad(B, prev, cur, dedx, bf ? wb[l] : weights[l], cfg->acc_double, dedy);
+        const float *yprev = (l == 1) ? (bf ? inb : in) : acts + act_offset(cfg, l - 1, B);
         wgrad(B, prev, cur, yprev, dedx, cfg->acc_double, grads_w[l], grads_b[l]);
     }
-    free(dedx); free(dedy);
+    free(dedx); free(dedy); free(inb);
+    for (int l = 1; l < L; ++l) free(wb[l]);
     if (own_acts) free(own_acts);
 }
 

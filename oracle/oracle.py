@@ -29,6 +29,7 @@ class OracleCfg(C.Structure):
         ("momentum_rule", C.c_int),
         ("acc_double", C.c_int),
         ("seed", C.c_uint64),
+        ("compute_dtype", C.c_int),
     ]
 
 
@@ -95,7 +96,7 @@ class Oracle:
 
     def __init__(self, layersizes, bunchsize, lrate=1.0, momentum=0.5, weightcost=0.0,
                  weights=None, bias=None, dropoutflag=0, visible_omit=0.0, hid_omit=0.0,
-                 activation=0, momentum_rule=0, acc_double=False, seed=0):
+                 activation=0, momentum_rule=0, acc_double=False, seed=0, compute_dtype=0):
         L = len(layersizes)
         assert 2 <= L <= MAXLAYER - 1
         self.layersizes = list(layersizes)
@@ -111,6 +112,7 @@ class Oracle:
         self.cfg.activation, self.cfg.momentum_rule = activation, momentum_rule
         self.cfg.acc_double = 1 if acc_double else 0
         self.cfg.seed = seed
+        self.cfg.compute_dtype = int(compute_dtype)      # 1 = bf16 operands (BASELINE configs[4])
         self.W = [None] + [np.array(weights[l], dtype=np.float32, order="C").reshape(
             layersizes[l - 1], layersizes[l]).copy() for l in range(1, L)]
         self.b = [None] + [np.array(bias[l], dtype=np.float32).reshape(layersizes[l]).copy()

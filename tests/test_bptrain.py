@@ -33,7 +33,7 @@ def test_bptrain_links_and_reports_errors_like_the_reference(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("act,rule,stack", [("relu", "live", "device"), ("sigmoid", "classic", "host"),
-                                            ("relu", "live", "host-noprefetch")])
+                                            ("relu", "live", "host-noprefetch"), ("relu", "live", "device-bf16")])
 def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule, stack):
     D, ctx, toff, seed, cache, B = 33, 3, 1, 345, 50, 16
     ls = [D * (ctx + 1), 64, D]                                                   # NAT block appended
@@ -57,7 +57,10 @@ def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule, 
             "activation=" + act, "momentum_rule=" + rule]
     # frame stacking on the device (default) or on the host (the reference's Readchunk layout), with / without the
     # read-ahead thread: the same samples reach the trainer in every mode
-    args += {"device": [], "host": ["stack=host"], "host-noprefetch": ["stack=host", "prefetch=0"]}[stack]
+    args += {"device": [], "host": ["stack=host"], "host-noprefetch": ["stack=host", "prefetch=0"],
+             "device-bf16": ["compute=bf16"]}[stack]           # bf16 GEMM operands: oracle in the same mode, 2e-2
+    bf16 = stack.endswith("bf16")
+    tol = 2e-2 if bf16 else TOL
     r = subprocess.run([_exe()] + args, capture_output=True, text=True)
     assert r.returncode == 1, r.stdout + r.stderr                                  # BPtrain.cc:100
     assert "all finish!" in r.stdout
@@ -69,7 +72,7 @@ def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule, 
     starts, total = PU.plan(fb, n, ctx, cache, 0, 7)
     order_chunks = PU.rand_index(len(starts), r48)
     o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, activation=1 if act == "sigmoid" else 0,
-                          momentum_rule=1 if rule == "classic" else 0)
+                          momentum_rule=1 if rule == "classic" else 0, compute_dtype=1 if bf16 else 0)
     log_lines = open(p["log"]).read()
     for i, ci in enumerate(order_chunks):
         cnt = total - cache * ci if ci == len(starts) - 1 else cache
@@ -79,7 +82,7 @@ def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule, 
         o.train(xin, xtg)
     Wg, bg = PU.read_wts(p["out"], ls)
     for l in (1, 2):
-        assert relerr(Wg[l], o.W[l]) < TOL and relerr(bg[l], o.b[l]) < TOL
+        assert relerr(Wg[l], o.W[l]) < tol and relerr(bg[l], o.b[l]) < tol
     cstarts, ctotal = PU.plan(fb, n, ctx, cache, 8, 9)
     sq = 0.0
     for ci in range(len(cstarts)):
@@ -88,7 +91,7 @@ def test_bptrain_epoch_matches_python_pipeline(tmp_path, oracle_mod, act, rule, 
                                  list(range(cnt)))
         sq += o.crossvalid(xin, xtg)
     m = re.search(r"CV over\. squared error: ([0-9.eE+-]+)", log_lines)             # the line the .pl greps for
-    assert m and abs(float(m.group(1)) - sq / ctotal) < 1e-3 * (sq / ctotal) + 1e-5
+    assert m and abs(float(m.group(1)) - sq / ctotal) < (tol if bf16 else 1e-3) * (sq / ctotal) + 1e-5
     for needle in ("parameters input:", "Please check...", "Norm file loaded.", "Init weight file loaded.",
                    "Get chunk info over: Training sentences have %d chunks, %d samples." % (len(starts), total),
                    "Saving over.", "Starting CV.", "Total cost time:", "Training pass: %d samples in" % total):
