@@ -47,67 +47,104 @@ struct BfEpiArgs {
     uint32_t drop_thresh, seed_lo, seed_hi, step, layer; int frame_off;
 };
 
-static constexpr int BF_BM = 64, BF_BN = 64, BF_BK = 64, BF_LDS = BF_BK + 8;   // LDS row stride in halfs (144 B: conflict-free b128)
+static constexpr int BF_BN = 64, BF_BK = 64, BF_LDS = BF_BK + 8;   // LDS row stride in halfs (144 B: conflict-free b128)
+static constexpr int BF_NPF = 3;                                     // k-tiles in flight in registers
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
+// BM = 64: 256 threads, waves 2 x 2.  BM = 32: 128 threads, waves 1 x 2 -- twice the workgroups for the M = bunch GEMMs.
+// The MFMA work per k-tile is tiny (4 x v_mfma_f32_32x32x16_bf16 per wave), so the loop is bound by the latency of the
+// tile loads: BF_NPF tiles are kept in flight in registers, two LDS stages, one barrier per k-tile.
+template <int EPI, int BM>
+__global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
 {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (BF_BM + BF_BN) * BF_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int tile_m = blockIdx.x % g.tiles_m, tile_n = blockIdx.x / g.tiles_m;
-    const int m0 = tile_m * BF_BM, n0 = tile_n * BF_BN;
-    // this thread's two 16-byte chunks of each operand tile: chunk c -> row c>>3, 8 halfs at column (c&7)*8
-    const int c0 = tid, c1 = tid + 256;
-    const int r0 = c0 >> 3, k0c = (c0 & 7) * 8, r1 = c1 >> 3, k1c = (c1 & 7) * 8;
-    const bf16_t *pa0 = g.A + (size_t)(m0 + r0) * g.lda + k0c, *pa1 = g.A + (size_t)(m0 + r1) * g.lda + k1c;
-    const bf16_t *pb0 = g.B + (size_t)(n0 + r0) * g.ldb + k0c, *pb1 = g.B + (size_t)(n0 + r1) * g.ldb + k1c;
-    auto As = [&](int st) { return smem + st * (BF_BM + BF_BN) * BF_LDS; };
-    auto Bs = [&](int st) { return smem + st * (BF_BM + BF_BN) * BF_LDS + BF_BM * BF_LDS; };
-
+    constexpr int NTHR = BM * 4, ROWS = BM + BF_BN, NCHK = ROWS * 8 / NTHR;     // 16-byte chunks per thread and tile
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ROWS * BF_LDS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = (BM == 64) ? wave >> 1 : 0, wn = wave & 1;
+    // XCD-aware tile map (block b runs on XCD b % 8): the workgroups that share a B panel (same tile_n, all tile_m)
+    // sit on one XCD, so the panel is fetched into that XCD's L2 once instead of eight times
+    int tile_m, tile_n;
+    if ((g.tiles_n & 7) == 0) {
+        const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = g.tiles_n >> 3;
+        tile_n = xcd * per + jj / g.tiles_m; tile_m = jj % g.tiles_m;
+    } else {
+        tile_m = blockIdx.x % g.tiles_m; tile_n = blockIdx.x / g.tiles_m;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BF_BN;
+    // chunk c of a tile: row c>>3 (rows [0, BM) from A, then BF_BN rows from B), 8 halfs at column (c&7)*8
+    const bf16_t *src[NCHK]; int dst[NCHK];
+#pragma unroll
+    for (int i = 0; i < NCHK; ++i) {
+        const int c = tid + i * NTHR, row = c >> 3, kc = (c & 7) * 8;
+        src[i] = row < BM ? g.A + (size_t)(m0 + row) * g.lda + kc : g.B + (size_t)(n0 + row - BM) * g.ldb + kc;
+        dst[i] = row * BF_LDS + kc;
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int nt = g.K / BF_BK;
-    uint4 ra0, ra1, rb0, rb1;
-#define BF_LOAD(t)                                                                                      \
+    // three register images of a tile, always addressed by name (a runtime-indexed array would live in scratch)
+    struct Img { uint4 v[NCHK]; };
+    Img r0, r1, r2;
+#define BF_LOAD(R, t)                                                                                   \
     do {                                                                                                \
-        const int kk_ = ((t) < nt ? (t) : nt - 1) * BF_BK;                                              \
-        ra0 = *reinterpret_cast<const uint4 *>(pa0 + kk_); ra1 = *reinterpret_cast<const uint4 *>(pa1 + kk_); \
-        rb0 = *reinterpret_cast<const uint4 *>(pb0 + kk_); rb1 = *reinterpret_cast<const uint4 *>(pb1 + kk_); \
+        const int kk_ = ((t) < nt ? (t) : nt - 1) * BF_BK;      /* unconditional, clamped */             \
+        _Pragma("unroll") for (int i = 0; i < NCHK; ++i) R.v[i] = *reinterpret_cast<const uint4 *>(src[i] + kk_); \
     } while (0)
-#define BF_STORE(st)                                                                                    \
+#define BF_STORE(R, st)                                                                                 \
     do {                                                                                                \
-        *reinterpret_cast<uint4 *>(As(st) + r0 * BF_LDS + k0c) = ra0; *reinterpret_cast<uint4 *>(As(st) + r1 * BF_LDS + k1c) = ra1; \
-        *reinterpret_cast<uint4 *>(Bs(st) + r0 * BF_LDS + k0c) = rb0; *reinterpret_cast<uint4 *>(Bs(st) + r1 * BF_LDS + k1c) = rb1; \
+        _Pragma("unroll") for (int i = 0; i < NCHK; ++i) { const uint4 v_ = R.v[i];                     \
+            *reinterpret_cast<uint4 *>(smem + (st) * ROWS * BF_LDS + dst[i]) = v_; }                    \
     } while (0)
-    BF_LOAD(0);
-    BF_STORE(0);
-    BF_LOAD(1);
+    const int arow = wm * 32 + (lane & 31), brow = BM + wn * 32 + (lane & 31), kh = (lane >> 5) * 8;
+// multiply tile t (LDS stage t&1); RN holds tile t+1: move it to the other stage and refill RN with tile t+1+NPF
+#define BF_ITER(t, RN)                                                                                  \
+    do {                                                                                                \
+        const bf16_t *base_ = smem + ((t) & 1) * ROWS * BF_LDS;                                         \
+        const bf16_t *ap_ = base_ + arow * BF_LDS + kh, *bp_ = base_ + brow * BF_LDS + kh;              \
+        const bf16x8_t a0_ = *reinterpret_cast<const bf16x8_t *>(ap_), a1_ = *reinterpret_cast<const bf16x8_t *>(ap_ + 16), \
+                       a2_ = *reinterpret_cast<const bf16x8_t *>(ap_ + 32), a3_ = *reinterpret_cast<const bf16x8_t *>(ap_ + 48); \
+        const bf16x8_t b0_ = *reinterpret_cast<const bf16x8_t *>(bp_), b1_ = *reinterpret_cast<const bf16x8_t *>(bp_ + 16), \
+                       b2_ = *reinterpret_cast<const bf16x8_t *>(bp_ + 32), b3_ = *reinterpret_cast<const bf16x8_t *>(bp_ + 48); \
+        BF_STORE(RN, ((t) + 1) & 1);               /* (past the last tile: a clamped duplicate nobody reads) */ \
+        BF_LOAD(RN, (t) + 1 + BF_NPF);                                                                  \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc, 0, 0, 0);                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc, 0, 0, 0);                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b2_, acc, 0, 0, 0);                          \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b3_, acc, 0, 0, 0);                          \
+        __syncthreads();                                                                                \
+    } while (0)
+    // tile t waits in image r(t % 3) until it is moved to LDS stage t & 1
+    BF_LOAD(r0, 0); BF_LOAD(r1, 1); BF_LOAD(r2, 2);
+    BF_STORE(r0, 0);
+    BF_LOAD(r0, BF_NPF);
     __syncthreads();
-    const int arow = wm * 32 + (lane & 31), brow = wn * 32 + (lane & 31), kh = (lane >> 5) * 8;
-    for (int t = 0; t < nt; ++t) {
-        const int st = t & 1;
-        const bf16_t *ap = As(st) + arow * BF_LDS + kh, *bp = Bs(st) + brow * BF_LDS + kh;
-        bf16x8_t av[4], bv[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            av[kk] = *reinterpret_cast<const bf16x8_t *>(ap + kk * 16);
-            bv[kk] = *reinterpret_cast<const bf16x8_t *>(bp + kk * 16);
-        }
-        if (t + 1 < nt) BF_STORE(st ^ 1);          // tile t+1 (landed) -> other stage
-        BF_LOAD(t + 2);                            // unconditional (clamped) prefetch
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kk], bv[kk], acc, 0, 0, 0);
-        __syncthreads();
-    }
+    int t = 0;
+    for (; t + 3 <= nt; t += 3) { BF_ITER(t, r1); BF_ITER(t + 1, r2); BF_ITER(t + 2, r0); }
+    if (t < nt) { BF_ITER(t, r1); if (t + 1 < nt) BF_ITER(t + 1, r2); }
 #undef BF_LOAD
 #undef BF_STORE
+#undef BF_ITER
 
     // ---- epilogue: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block
     const int n = n0 + wn * 32 + (lane & 31);
-    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);
+    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);   // (wm = 0 for BM = 32)
     if (n >= e.n_limit) return;
     const bool live = n < e.n_true;
+    // Everything the epilogue READS is gathered into registers first, in one burst: the stores below go through
+    // pointers the compiler must assume may alias the inputs, so a load placed after a store would wait for it --
+    // 16 serialised memory round trips per lane instead of one.
+    float in0[16], in1[16];                           // fwd_out: targ | dgrad: y_{l-1} | wgrad update: W, delta
+    float bn = 0.0f;
+    if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_FWD_OUT) bn = e.bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = rbase + (r & 3) + 8 * (r >> 2);
+        in0[r] = 0.0f; in1[r] = 0.0f;
+        if (m < e.m_limit) {
+            if constexpr (EPI == BEPI_FWD_OUT) { if (e.C && live) in0[r] = e.targ[(size_t)m * e.ldt + n]; }
+            if constexpr (EPI == BEPI_DGRAD) in0[r] = bf2f(e.yprev[(size_t)m * e.ldy + n]);
+            if constexpr (EPI == BEPI_WGRAD_UPDATE) { in0[r] = e.W[(size_t)m * e.ldw + n]; in1[r] = e.D[(size_t)m * e.ldw + n]; }
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int mq = rbase + 8 * q;                 // 4 consecutive rows mq..mq+3 (mq % 4 == 0)
@@ -120,7 +157,6 @@ __global__ __launch_bounds__(256, 2) void bp_gemm_bf16(const BfGemmArgs g, const
                 w[0] = (uint32_t)idx; w[1] = (uint32_t)(idx >> 32); w[2] = e.layer; w[3] = e.step;
                 philox4x32_10(w[0], w[1], w[2], w[3], e.seed_lo, e.seed_hi);
             }
-            const float bn = e.bias[n];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float y = act_fwd(e.act, e.alpha * acc[4 * q + j] + bn);
@@ -128,7 +164,6 @@ __global__ __launch_bounds__(256, 2) void bp_gemm_bf16(const BfGemmArgs g, const
                 v[j] = y;
             }
         } else if constexpr (EPI == BEPI_FWD_OUT) {
-            const float bn = e.bias[n];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int m = mq + j;
@@ -136,17 +171,15 @@ __global__ __launch_bounds__(256, 2) void bp_gemm_bf16(const BfGemmArgs g, const
                 if (m < e.m_limit) {
                     const float o = live ? e.alpha * acc[4 * q + j] + bn : 0.0f;
                     if (e.out) e.out[(size_t)m * e.ldo + n] = o;
-                    if (e.C && live) d = e.scale * (o - e.targ[(size_t)m * e.ldt + n]);      // kernSubClean
+                    if (e.C && live) d = e.scale * (o - in0[4 * q + j]);                     // kernSubClean
                 }
                 v[j] = d;
             }
             if (!e.C) continue;
         } else if constexpr (EPI == BEPI_DGRAD) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = mq + j;
-                v[j] = (m < e.m_limit && live) ? act_bwd(e.act, bf2f(e.yprev[(size_t)m * e.ldy + n])) * acc[4 * q + j] : 0.0f;
-            }
+            for (int j = 0; j < 4; ++j)
+                v[j] = (mq + j < e.m_limit && live) ? act_bwd(e.act, in0[4 * q + j]) * acc[4 * q + j] : 0.0f;
         } else {                                      // wgrad: rows = units of layer l-1, cols = units of layer l
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -154,10 +187,10 @@ __global__ __launch_bounds__(256, 2) void bp_gemm_bf16(const BfGemmArgs g, const
                 if (m >= e.m_limit) { v[j] = 0.0f; continue; }
                 const size_t i = (size_t)m * e.ldw + n;
                 if constexpr (EPI == BEPI_WGRAD_UPDATE) {
-                    const float w = e.W[i];
-                    const float d = e.mom * e.D[i] - e.c1 * (acc[4 * q + j] / e.ndiv + e.wc * w);   // kernUpdatedelta
+                    const float w = in0[4 * q + j];
+                    const float d = e.mom * in1[4 * q + j] - e.c1 * (acc[4 * q + j] / e.ndiv + e.wc * w);   // kernUpdatedelta
                     e.D[i] = d;
-                    v[j] = d + 1.0f * w;                                                            // kernAccSum
+                    v[j] = d + 1.0f * w;                                                                    // kernAccSum
                     e.W[i] = v[j];
                 } else {
                     e.W[i] = acc[4 * q + j];          // gradient into the flat buffer (data parallel)
@@ -205,10 +238,28 @@ __global__ void bp_to_bf16_both(const float *src, int lds, int rows, int cols, b
 __global__ void bp_bias_bf16(const bf16_t *dx, int ld, int rows, int n_true, float *bias, float *dbias, float *gout,
                              float mom, float c1, float ndiv)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= n_true) return;
+    // block = 64 columns x 16 row groups (the kernel is pure load latency: many rows in flight); fixed summation
+    // order (row groups folded 0..15) => deterministic
+    __shared__ float part[16][64];
+    const int n = blockIdx.x * 64 + threadIdx.x;
     float s = 0.0f;
-    for (int f = 0; f < rows; ++f) s += bf2f(dx[(size_t)f * ld + n]);
+    if (n < n_true) {
+        int f = threadIdx.y;
+        for (; f + 112 < rows; f += 128) {            // 8 independent loads in flight, summed in a fixed order
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = bf2f(dx[(size_t)(f + 16 * u) * ld + n]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; f < rows; f += 16) s += bf2f(dx[(size_t)f * ld + n]);
+    }
+    part[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y != 0 || n >= n_true) return;
+    s = 0.0f;
+#pragma unroll
+    for (int y = 0; y < 16; ++y) s += part[y][threadIdx.x];
     if (gout) { gout[n] = s; return; }
     const float d = mom * dbias[n] - c1 * (s / ndiv + 0.0f * bias[n]);
     dbias[n] = d;

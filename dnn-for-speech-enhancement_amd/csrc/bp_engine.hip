@@ -433,10 +433,18 @@ static hipError_t bf_shadow(bp_handle *h, int l)
     const int prev = h->ld[l - 1], cur = h->ld[l];
     return bf_convert(h, h->W[l], cur, prev, cur, h->Wb[l], cur, h->WbT[l], prev, prev, cur);
 }
+// BM = 32 tiles (128-thread workgroups) when 64-row tiles would leave CUs without work
 template <int EPI>
-static hipError_t bf_launch(bp_handle *h, const BfGemmArgs &g, const BfEpiArgs &e)
+static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int M, int N)
 {
-    hipLaunchKernelGGL((bp_gemm_bf16<EPI>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
+    g.tiles_n = N / 64;
+    if ((M / 64) * g.tiles_n >= 512) {
+        g.tiles_m = M / 64;
+        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 64>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
+    } else {
+        g.tiles_m = M / 32;
+        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 32>), dim3(g.tiles_m * g.tiles_n), dim3(128), 0, h->stream, g, e);
+    }
     return hipGetLastError();
 }
 // forward of weight layer l on M frames (bf16 operands); train: hidden outputs get the hid_omit mask, the output
@@ -445,7 +453,7 @@ static hipError_t bf_fwd(bp_handle *h, int l, int M, const float *targ, float *o
 {
     const int L = h->L, prev = h->ld[l - 1], cur = h->ld[l];
     BfGemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = h->yb[l - 1]; g.lda = prev; g.B = h->WbT[l]; g.ldb = prev; g.K = prev; g.tiles_m = h->Bp / 64; g.tiles_n = cur / 64;
+    g.A = h->yb[l - 1]; g.lda = prev; g.B = h->WbT[l]; g.ldb = prev; g.K = prev;
     BfEpiArgs e; memset(&e, 0, sizeof(e));
     e.m_limit = M; e.n_limit = cur; e.n_true = h->s[l]; e.bias = h->b[l]; e.alpha = alpha; e.act = h->cfg.activation;
     e.ldc = cur; e.ldct = h->Bp;
@@ -454,12 +462,12 @@ static hipError_t bf_fwd(bp_handle *h, int l, int M, const float *targ, float *o
         e.drop_thresh = train ? h->th_hid : 0u;
         e.seed_lo = (uint32_t)h->cfg.seed; e.seed_hi = (uint32_t)(h->cfg.seed >> 32);
         e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
-        return bf_launch<BEPI_FWD_HIDDEN>(h, g, e);
+        return bf_launch<BEPI_FWD_HIDDEN>(h, g, e, h->Bp, cur);
     }
     e.scale = 2.0f / (float)h->Bg;
     e.targ = targ; e.ldt = cur; e.out = out; e.ldo = cur;
     if (train) { e.C = h->dxb[l]; e.CT = h->dxbT[l]; }
-    return bf_launch<BEPI_FWD_OUT>(h, g, e);
+    return bf_launch<BEPI_FWD_OUT>(h, g, e, h->Bp, cur);
 }
 static hipError_t bf_input(bp_handle *h, const float *x0, int M)
 {
@@ -475,16 +483,16 @@ static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool 
     for (int l = L - 1; l >= 2; --l) {               // dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T), pre-update weights
         const int prev = h->ld[l - 1], cur = h->ld[l];
         BfGemmArgs g; memset(&g, 0, sizeof(g));
-        g.A = h->dxb[l]; g.lda = cur; g.B = h->Wb[l]; g.ldb = cur; g.K = cur; g.tiles_m = h->Bp / 64; g.tiles_n = prev / 64;
+        g.A = h->dxb[l]; g.lda = cur; g.B = h->Wb[l]; g.ldb = cur; g.K = cur;
         BfEpiArgs e; memset(&e, 0, sizeof(e));
         e.m_limit = B; e.n_limit = prev; e.n_true = h->s[l - 1]; e.act = h->cfg.activation;
         e.C = h->dxb[l - 1]; e.ldc = prev; e.CT = h->dxbT[l - 1]; e.ldct = h->Bp; e.yprev = h->yb[l - 1]; e.ldy = prev;
-        CKE(bf_launch<BEPI_DGRAD>(h, g, e));
+        CKE(bf_launch<BEPI_DGRAD>(h, g, e, h->Bp, prev));
     }
     for (int l = 1; l < L; ++l) {                    // G_l = y_{l-1}^T . dEdX_l  (+ update / store), bias gradient
         const int prev = h->ld[l - 1], cur = h->ld[l];
         BfGemmArgs g; memset(&g, 0, sizeof(g));
-        g.A = h->ybT[l - 1]; g.lda = h->Bp; g.B = h->dxbT[l]; g.ldb = h->Bp; g.K = h->Bp; g.tiles_m = prev / 64; g.tiles_n = cur / 64;
+        g.A = h->ybT[l - 1]; g.lda = h->Bp; g.B = h->dxbT[l]; g.ldb = h->Bp; g.K = h->Bp;
         BfEpiArgs e; memset(&e, 0, sizeof(e));
         e.m_limit = prev; e.n_limit = cur; e.n_true = h->s[l]; e.ldw = cur;
         const float m = h->cfg.momentum, lr = h->cfg.lrate;
@@ -492,12 +500,12 @@ static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool 
         if (fused) {
             e.W = h->W[l]; e.D = h->dW[l]; e.mom = m; e.c1 = c1; e.wc = h->cfg.weightcost; e.ndiv = (float)h->Bg;
             e.C = h->Wb[l]; e.ldc = cur; e.CT = h->WbT[l]; e.ldct = prev;
-            CKE(bf_launch<BEPI_WGRAD_UPDATE>(h, g, e));
+            CKE(bf_launch<BEPI_WGRAD_UPDATE>(h, g, e, prev, cur));
         } else {
             e.W = h->grad + h->g_off[l];
-            CKE(bf_launch<BEPI_WGRAD_STORE>(h, g, e));
+            CKE(bf_launch<BEPI_WGRAD_STORE>(h, g, e, prev, cur));
         }
-        hipLaunchKernelGGL(bp_bias_bf16, dim3((h->s[l] + 255) / 256), dim3(256), 0, h->stream, h->dxb[l], cur, B, h->s[l],
+        hipLaunchKernelGGL(bp_bias_bf16, dim3((h->s[l] + 63) / 64), dim3(64, 16), 0, h->stream, h->dxb[l], cur, B, h->s[l],
                            h->b[l], h->db[l], fused ? (float *)nullptr : h->grad + h->g_off[l] + (size_t)prev * cur, m, c1,
                            (float)h->Bg);
         CKE(hipGetLastError());
