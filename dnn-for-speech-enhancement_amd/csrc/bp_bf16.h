@@ -77,6 +77,30 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
         src[i] = row < BM ? g.A + (size_t)(m0 + row) * g.lda + kc : g.B + (size_t)(n0 + row - BM) * g.ldb + kc;
         dst[i] = row * BF_LDS + kc;
     }
+    // ---- epilogue mapping: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block
+    const int n = n0 + wn * 32 + (lane & 31);
+    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);   // (wm = 0 for BM = 32)
+    const bool live = n < e.n_true;
+    // Everything the epilogue READS (targets | y_{l-1} | W, delta) is fetched here, BEFORE the k-loop, in one burst: its
+    // latency hides under the loop (wgrad has only bunch/64 k-tiles, so a workgroup is otherwise one round trip for
+    // the tiles plus one for W/delta), and no load has to wait behind the epilogue's stores, which go through
+    // pointers the compiler must assume may alias the inputs.
+    float in0[16], in1[16];
+    float bn = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { in0[r] = 0.0f; in1[r] = 0.0f; }
+    if (n < e.n_limit) {
+        if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_FWD_OUT) bn = e.bias[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = rbase + (r & 3) + 8 * (r >> 2);
+            if (m < e.m_limit) {
+                if constexpr (EPI == BEPI_FWD_OUT) { if (e.C && live) in0[r] = e.targ[(size_t)m * e.ldt + n]; }
+                if constexpr (EPI == BEPI_DGRAD) in0[r] = bf2f(e.yprev[(size_t)m * e.ldy + n]);
+                if constexpr (EPI == BEPI_WGRAD_UPDATE) { in0[r] = e.W[(size_t)m * e.ldw + n]; in1[r] = e.D[(size_t)m * e.ldw + n]; }
+            }
+        }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -124,27 +148,8 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
 #undef BF_STORE
 #undef BF_ITER
 
-    // ---- epilogue: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block
-    const int n = n0 + wn * 32 + (lane & 31);
-    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);   // (wm = 0 for BM = 32)
+    // ---- epilogue
     if (n >= e.n_limit) return;
-    const bool live = n < e.n_true;
-    // Everything the epilogue READS is gathered into registers first, in one burst: the stores below go through
-    // pointers the compiler must assume may alias the inputs, so a load placed after a store would wait for it --
-    // 16 serialised memory round trips per lane instead of one.
-    float in0[16], in1[16];                           // fwd_out: targ | dgrad: y_{l-1} | wgrad update: W, delta
-    float bn = 0.0f;
-    if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_FWD_OUT) bn = e.bias[n];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = rbase + (r & 3) + 8 * (r >> 2);
-        in0[r] = 0.0f; in1[r] = 0.0f;
-        if (m < e.m_limit) {
-            if constexpr (EPI == BEPI_FWD_OUT) { if (e.C && live) in0[r] = e.targ[(size_t)m * e.ldt + n]; }
-            if constexpr (EPI == BEPI_DGRAD) in0[r] = bf2f(e.yprev[(size_t)m * e.ldy + n]);
-            if constexpr (EPI == BEPI_WGRAD_UPDATE) { in0[r] = e.W[(size_t)m * e.ldw + n]; in1[r] = e.D[(size_t)m * e.ldw + n]; }
-        }
-    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int mq = rbase + 8 * q;                 // 4 consecutive rows mq..mq+3 (mq % 4 == 0)

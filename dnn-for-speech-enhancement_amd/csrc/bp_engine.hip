@@ -364,7 +364,10 @@ static hipError_t run_multi(hipStream_t st, Prepared *ps, int n)
     for (int i = 0; i < n; ++i) {
         ps[i].g.tiles_m = (ps[i].M + BMT - 1) / BMT; ps[i].g.tiles_n = (ps[i].N + BNT - 1) / BNT;
         a.g[i] = ps[i].g; a.e[i] = ps[i].e; a.first_tile[i] = t;
-        t += ps[i].g.tiles_m * ps[i].g.tiles_n;
+        // every problem starts on a multiple of 8 workgroups: its problem-relative block index then has the same
+        // low 3 bits as the hardware's blockIdx (= the XCD), which the XCD-aware tile map inside run() relies on
+        // (the up-to-7 padding workgroups find no tile and exit)
+        t += (ps[i].g.tiles_m * ps[i].g.tiles_n + 7) & ~7;
     }
     a.first_tile[n] = t; a.n = n;
     hipLaunchKernelGGL((bp_gemm_multi<K>), dim3(t), dim3(256), 0, st, a);
