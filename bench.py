@@ -68,7 +68,6 @@ def main():
 
     import torch
     import dnnse_amd
-    from oracle import bp_numpy as N_        # weight-init recipe only (Gen_rand_net flag=1 beta=0.5)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,7 +86,7 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     dev = local_rank
 
-    W, b = N_.glorot_net(LAYERS, seed=1, beta=0.5)
+    W, b = dnnse_amd.glorot_net(LAYERS, seed=1, beta=0.5)    # Gen_rand_net flag=1, beta=0.5 recipe
     chunk = max(BUNCH, (args.chunk // BUNCH) * BUNCH)
     kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=20260927, device=dev, max_chunk_frames=chunk)
 

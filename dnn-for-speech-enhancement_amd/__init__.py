@@ -3,3 +3,4 @@
 `libbp_hip.so` behind the C ABI in include/bp_c_api.h; this package is its Python host mirror.
 (The directory name contains '-', import it through `dnnse_amd.py` at the repo root.)"""
 from .bp_gpu import BP_GPU, BPError, BPConfig, load_library, LIB_PATH, ABI_SYMBOLS, MAXLAYER, MAXCACHEFRAME  # noqa: F401
+from .weights_init import glorot_net  # noqa: F401

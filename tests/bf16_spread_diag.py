@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')  # run from the repo root: python tests/bf16_spread_diag.py
 import numpy as np
 import dnnse_amd as pkg
 from oracle import oracle as O, bp_numpy as N

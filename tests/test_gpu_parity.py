@@ -417,7 +417,7 @@ def test_bf16_config5_shape_one_step(pkg, oracle_mod):
     """BASELINE.json configs[4] per-GPU shape: 2827 -> 4096 x 5 -> 257, 512 frames, ReLU, no dropout; one step.
     At this depth and width two correct bf16 implementations that only differ in summation order already disagree by
     2-3 % (rms) on the back-propagated gradients (rounding / ReLU boundaries falling differently compound over five
-    hidden layers: the oracle with fp32 and with fp64 accumulation shows exactly that spread, tools/bf16_diag.py), so
+    hidden layers: the oracle with fp32 and with fp64 accumulation shows exactly that spread, tests/bf16_spread_diag.py), so
     the gradient bound is 2e-2 plus that measured spread; outputs and weights keep the plain 2e-2."""
     ls, B = [2827, 4096, 4096, 4096, 4096, 4096, 257], 512
     W, b = N.glorot_net(ls, seed=1, beta=0.5)

@@ -8,11 +8,10 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dnnse_amd  # noqa: E402
-from oracle import bp_numpy as N_  # noqa: E402
 
 
 def run(name, ls, B, dtype, steps=100, drop=True):
-    W, b = N_.glorot_net(ls, seed=1, beta=0.5)
+    W, b = dnnse_amd.glorot_net(ls, seed=1, beta=0.5)
     kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=1) if drop else {}
     chunk = B * 50
     g = dnnse_amd.BP_GPU(1, len(ls), ls, B, 0.01, 0.5, 0.0, W, b, max_chunk_frames=chunk, compute_dtype=dtype, **kw)
