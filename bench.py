@@ -186,6 +186,10 @@ def main():
                            "achieved": ach, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TF,
                            "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
                            "algorithmic_bytes": 4.0 * (2048 * 2048 + 2 * BUNCH * 2048), "kernel_ms": ms,
+                           # skinny layers: achieved GB/s = 4*(prev*cur + B*prev + B*cur) / t
+                           "skinny_layers_GBs": {
+                               "fwd_l1_2827x2048": 4.0 * (LAYERS[0] * LAYERS[1] + BUNCH * (LAYERS[0] + LAYERS[1])) / (ms["fwd_l1"] * 1e-3) / 1e9,
+                               "fwd_out_2048x257": 4.0 * (LAYERS[-2] * LAYERS[-1] + BUNCH * (LAYERS[-2] + LAYERS[-1])) / (ms["fwd_out"] * 1e-3) / 1e9},
                            "step_frac_of_mfma_peak": flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF}
         if world == 1 and not force_dp and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, b)
