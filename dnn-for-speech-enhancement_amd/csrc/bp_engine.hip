@@ -476,43 +476,51 @@ static hipError_t bf_input(bp_handle *h, const float *x0, int M)
 {
     return bf_convert(h, x0, h->ld[0], M, h->ld[0], h->yb[0], h->ld[0], h->ybT[0], h->Bp, h->Bp, h->ld[0]);
 }
+// dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T), pre-update weights
+static hipError_t bf_dgrad(bp_handle *h, int l)
+{
+    const int prev = h->ld[l - 1], cur = h->ld[l];
+    BfGemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = h->dxb[l]; g.lda = cur; g.B = h->Wb[l]; g.ldb = cur; g.K = cur;
+    BfEpiArgs e; memset(&e, 0, sizeof(e));
+    e.m_limit = h->B; e.n_limit = prev; e.n_true = h->s[l - 1]; e.act = h->cfg.activation;
+    e.C = h->dxb[l - 1]; e.ldc = prev; e.CT = h->dxbT[l - 1]; e.ldct = h->Bp; e.yprev = h->yb[l - 1]; e.ldy = prev;
+    return bf_launch<BEPI_DGRAD>(h, g, e, h->Bp, prev);
+}
+// G_l = y_{l-1}^T . dEdX_l  (+ fused update and shadow refresh, or store into the flat buffer), bias gradient
+static hipError_t bf_wgrad(bp_handle *h, int l, bool fused)
+{
+    const int prev = h->ld[l - 1], cur = h->ld[l];
+    hipError_t er;
+    BfGemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = h->ybT[l - 1]; g.lda = h->Bp; g.B = h->dxbT[l]; g.ldb = h->Bp; g.K = h->Bp;
+    BfEpiArgs e; memset(&e, 0, sizeof(e));
+    e.m_limit = prev; e.n_limit = cur; e.n_true = h->s[l]; e.ldw = cur;
+    const float m = h->cfg.momentum, lr = h->cfg.lrate;
+    const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
+    if (fused) {
+        e.W = h->W[l]; e.D = h->dW[l]; e.mom = m; e.c1 = c1; e.wc = h->cfg.weightcost; e.ndiv = (float)h->Bg;
+        e.C = h->Wb[l]; e.ldc = cur; e.CT = h->WbT[l]; e.ldct = prev;
+        er = bf_launch<BEPI_WGRAD_UPDATE>(h, g, e, prev, cur);
+    } else {
+        e.W = h->grad + h->g_off[l];
+        er = bf_launch<BEPI_WGRAD_STORE>(h, g, e, prev, cur);
+    }
+    if (er != hipSuccess) return er;
+    hipLaunchKernelGGL(bp_bias_bf16, dim3((h->s[l] + 63) / 64), dim3(64, 16), 0, h->stream, h->dxb[l], cur, h->B, h->s[l],
+                       h->b[l], h->db[l], fused ? (float *)nullptr : h->grad + h->g_off[l] + (size_t)prev * cur, m, c1,
+                       (float)h->Bg);
+    return hipGetLastError();
+}
 static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool fused)
 {
-    const int L = h->L, B = h->B;
+    const int L = h->L;
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
-    CKE(bf_input(h, x0, B));
-    for (int l = 1; l < L; ++l) CKE(bf_fwd(h, l, B, tg, nullptr, true, 1.0f));
-    for (int l = L - 1; l >= 2; --l) {               // dEdX_{l-1} = act'(y_{l-1}) * (dEdX_l . W_l^T), pre-update weights
-        const int prev = h->ld[l - 1], cur = h->ld[l];
-        BfGemmArgs g; memset(&g, 0, sizeof(g));
-        g.A = h->dxb[l]; g.lda = cur; g.B = h->Wb[l]; g.ldb = cur; g.K = cur;
-        BfEpiArgs e; memset(&e, 0, sizeof(e));
-        e.m_limit = B; e.n_limit = prev; e.n_true = h->s[l - 1]; e.act = h->cfg.activation;
-        e.C = h->dxb[l - 1]; e.ldc = prev; e.CT = h->dxbT[l - 1]; e.ldct = h->Bp; e.yprev = h->yb[l - 1]; e.ldy = prev;
-        CKE(bf_launch<BEPI_DGRAD>(h, g, e, h->Bp, prev));
-    }
-    for (int l = 1; l < L; ++l) {                    // G_l = y_{l-1}^T . dEdX_l  (+ update / store), bias gradient
-        const int prev = h->ld[l - 1], cur = h->ld[l];
-        BfGemmArgs g; memset(&g, 0, sizeof(g));
-        g.A = h->ybT[l - 1]; g.lda = h->Bp; g.B = h->dxbT[l]; g.ldb = h->Bp; g.K = h->Bp;
-        BfEpiArgs e; memset(&e, 0, sizeof(e));
-        e.m_limit = prev; e.n_limit = cur; e.n_true = h->s[l]; e.ldw = cur;
-        const float m = h->cfg.momentum, lr = h->cfg.lrate;
-        const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
-        if (fused) {
-            e.W = h->W[l]; e.D = h->dW[l]; e.mom = m; e.c1 = c1; e.wc = h->cfg.weightcost; e.ndiv = (float)h->Bg;
-            e.C = h->Wb[l]; e.ldc = cur; e.CT = h->WbT[l]; e.ldct = prev;
-            CKE(bf_launch<BEPI_WGRAD_UPDATE>(h, g, e, prev, cur));
-        } else {
-            e.W = h->grad + h->g_off[l];
-            CKE(bf_launch<BEPI_WGRAD_STORE>(h, g, e, prev, cur));
-        }
-        hipLaunchKernelGGL(bp_bias_bf16, dim3((h->s[l] + 63) / 64), dim3(64, 16), 0, h->stream, h->dxb[l], cur, B, h->s[l],
-                           h->b[l], h->db[l], fused ? (float *)nullptr : h->grad + h->g_off[l] + (size_t)prev * cur, m, c1,
-                           (float)h->Bg);
-        CKE(hipGetLastError());
-    }
+    CKE(bf_input(h, x0, h->B));
+    for (int l = 1; l < L; ++l) CKE(bf_fwd(h, l, h->B, tg, nullptr, true, 1.0f));
+    for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));       // every dgrad sees pre-update (shadow) weights
+    for (int l = 1; l < L; ++l) CKE(bf_wgrad(h, l, fused));
 #undef CKE
     return hipSuccess;
 }
@@ -761,7 +769,6 @@ static hipError_t dp_input(bp_handle *h, int first, const float **x0)
 extern "C" int bp_dp_forward_layer(bp_handle *h, int first_frame, int layer)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_forward_layer: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_forward_layer: layer out of range");
     if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_dp_forward_layer: bunch outside the resident chunk");
@@ -772,7 +779,12 @@ extern "C" int bp_dp_forward_layer(bp_handle *h, int first_frame, int layer)
     const float *x0;
     HIPCHK(dp_input(h, first_frame, &x0));
     const float *tg = h->targ + (size_t)first_frame * h->ld[h->L - 1];
-    HIPCHK(launch_fwd(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], tg, nullptr, true, 1.0f));
+    if (h->bf) {
+        if (layer == 1) HIPCHK(bf_input(h, x0, h->B));
+        HIPCHK(bf_fwd(h, layer, h->B, tg, nullptr, true, 1.0f));
+    } else {
+        HIPCHK(launch_fwd(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], tg, nullptr, true, 1.0f));
+    }
     h->dp_first = first_frame; h->dp_fwd_next = layer + 1;
     h->dp_next_layer = (layer == h->L - 1) ? h->L - 1 : 0;     // backward may start after the output layer
     return BP_OK;
@@ -789,10 +801,11 @@ extern "C" int bp_dp_forward(bp_handle *h, int first_frame)
 extern "C" int bp_dp_dgrads(bp_handle *h)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_dgrads: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (h->dp_next_layer != h->L - 1) return fail(BP_ERR_STATE, "bp_dp_dgrads: run the forward of a bunch first");
     HIPCHK(hipSetDevice(h->cfg.device));
-    for (int l = h->L - 1; l >= 2; --l) HIPCHK(launch_dgrad(h, h->stream, l, h->B));
+    for (int l = h->L - 1; l >= 2; --l) {
+        if (h->bf) HIPCHK(bf_dgrad(h, l)); else HIPCHK(launch_dgrad(h, h->stream, l, h->B));
+    }
     h->dp_next_layer = -1;                                     // wgrads may now come in any order
     return BP_OK;
 }
@@ -800,10 +813,10 @@ extern "C" int bp_dp_dgrads(bp_handle *h)
 extern "C" int bp_dp_wgrad_layer(bp_handle *h, int layer)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_wgrad_layer: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_wgrad_layer: layer out of range");
     if (h->dp_next_layer != -1) return fail(BP_ERR_STATE, "bp_dp_wgrad_layer: call bp_dp_dgrads first");
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->bf) { HIPCHK(bf_wgrad(h, layer, false)); return BP_OK; }
     const float *x0;
     HIPCHK(dp_input(h, h->dp_first, &x0));
     HIPCHK(launch_wgrad(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], false));
@@ -813,11 +826,16 @@ extern "C" int bp_dp_wgrad_layer(bp_handle *h, int layer)
 extern "C" int bp_dp_backward_layer(bp_handle *h, int layer)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (h->bf) return fail(BP_ERR_STATE, "bp_dp_backward_layer: the layer-by-layer data-parallel calls are fp32 only (bf16: bp_grads_resident + bp_apply_update)");
     if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_backward_layer: layer out of range");
     if (layer != h->dp_next_layer)
         return fail(BP_ERR_STATE, "bp_dp_backward_layer: call bp_dp_forward first, then layers numlayers-1 ... 1 in order");
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->bf) {
+        if (layer != 1) HIPCHK(bf_dgrad(h, layer));
+        HIPCHK(bf_wgrad(h, layer, false));
+        h->dp_next_layer = layer - 1;
+        return BP_OK;
+    }
     const float *x0;
     HIPCHK(dp_input(h, h->dp_first, &x0));
     if (layer != 1) HIPCHK(launch_dgrad(h, h->stream, layer, h->B));
@@ -828,14 +846,6 @@ extern "C" int bp_dp_backward_layer(bp_handle *h, int layer)
 
 extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
 {
-    if (h && h->bf) {            // bf16 operands: whole bunch at once, gradients (fp32) to the flat buffer
-        if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
-            return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
-        HIPCHK(hipSetDevice(h->cfg.device));
-        if (!h->grad) { int r0 = dev_alloc(h, &h->grad, h->grad_floats); if (r0 != BP_OK) return r0; }
-        HIPCHK(bunch(h, first_frame, false));
-        return BP_OK;
-    }
     int r = bp_dp_forward(h, first_frame);
     for (int l = h ? h->L - 1 : 0; r == BP_OK && l >= 1; --l) r = bp_dp_backward_layer(h, l);
     return r;

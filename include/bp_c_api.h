@@ -67,9 +67,8 @@ typedef struct bp_config {
                                        (activations, errors, a shadow copy of the weights) with fp32
                                        accumulation, fp32 master weights / momentum / update
                                        (BASELINE.json configs[4]); parity tolerance 2e-2 instead of
-                                       1e-4.  Supported calls in this mode: train / cv / forward /
-                                       bp_train_resident, bp_grads_resident + bp_apply_update,
-                                       weights and deltas download                               */
+                                       1e-4.  Every call works in this mode except
+                                       bp_time_kernel (fp32 kernels only)                        */
 } bp_config;
 
 typedef struct bp_handle bp_handle;

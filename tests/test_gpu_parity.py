@@ -408,9 +408,27 @@ def test_bf16_gradient_split_equals_fused_step(pkg):
     (w1, b1), (w2, b2) = g1.get_weights(), g2.get_weights()
     for l in range(1, len(ls)):
         assert relerr(w1[l], w2[l]) < 1e-6 and relerr(b1[l], b2[l]) < 1e-6
-    with pytest.raises(pkg.BPError):
-        g2.dp_forward_layer(0, 1)                                  # layer-wise calls are fp32 only
-    g1.close(); g2.close()
+    # the cross-step pipeline order of dp.DPPipeline (layer-by-layer calls) in bf16: same result again
+    g3 = _mk(pkg, ls, B, W, b, lr=0.5, **kw)
+    g3.upload_chunk(x, t)
+    L = len(ls)
+    for i in range(3):
+        if i:
+            g3.advance_step()
+        for l in range(1, L):
+            if i:
+                g3.apply_update_layer(l)
+            g3.dp_forward_layer(i * B, l)
+        g3.dp_dgrads()
+        for l in range(1, L):
+            g3.dp_wgrad_layer(l)
+    for l in range(1, L):
+        g3.apply_update_layer(l)
+    g3.advance_step()
+    w3, b3 = g3.get_weights()
+    for l in range(1, L):
+        assert np.array_equal(w3[l], w2[l]) and np.array_equal(b3[l], b2[l])
+    g1.close(); g2.close(); g3.close()
 
 
 def test_bf16_config5_shape_one_step(pkg, oracle_mod):
