@@ -97,7 +97,7 @@ int main(int argc, char **argv)
     WGR(64, 128, 16, 2, 2, 1, 0); WGR(64, 128, 16, 2, 2, 1, 256);
     WGR(128, 128, 16, 2, 2, 1, 0); WGR(128, 128, 16, 2, 2, 1, 128);
 #define WGS(BM, BN, BK, WM, WN, NT) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " static" #NT " grid0", [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, 1, NT>(s, g, e, H, H, 0); }, 2.0 * H * H * (double)KW})
-    WGS(128, 64, 16, 2, 2, 16); WGS(64, 64, 32, 2, 2, 8); WGS(64, 64, 16, 2, 2, 16); WGS(64, 128, 16, 2, 2, 16); WGS(128, 64, 32, 2, 2, 8); WGS(128, 128, 16, 2, 2, 16);
+    WGS(64, 64, 64, 2, 2, 4); WGS(128, 64, 16, 2, 2, 16); WGS(64, 64, 32, 2, 2, 8); WGS(64, 64, 16, 2, 2, 16); WGS(64, 128, 16, 2, 2, 16); WGS(128, 64, 32, 2, 2, 8); WGS(128, 128, 16, 2, 2, 16);
     // calibration: what the matrix pipe delivers on this box (one wave per SIMD, 256 workgroups)
     vs.push_back({"mfma peak: 1 dependent chain/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<1>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0});
     vs.push_back({"mfma peak: 4 chains/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<4>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0 * 4});
