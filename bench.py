@@ -193,6 +193,11 @@ def main():
                            "step_frac_of_mfma_peak": flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF}
         if world == 1 and not force_dp and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, b)
+        try:                                   # anything native code left in C stdio (e.g. the RCCL banner) goes out first,
+            import ctypes                      # so that the JSON line is the last thing on stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
