@@ -135,6 +135,10 @@ __device__ __forceinline__ T *sgpr_row_base(T *p)
 #define BP_STORE_SLOT(q, NK, NP) (((q) * (NK)) / (NP))
 #endif
 
+#ifndef BP_WGRAD_NFAST
+#define BP_WGRAD_NFAST 1
+#endif
+
 // wgrad block orientation.  1: the natural MFMA layout (lane -> column n, registers -> rows): every
 // W / delta load and store is two full 128-byte rows.  0: transposed block (operands swapped in the
 // MFMA), lane -> row m and 4 registers -> 4 consecutive columns: float4 accesses, but each
@@ -611,8 +615,19 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     {
         if ((g.tiles_n & 7) == 0) {
             const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3;
-            tile_n = xcd * per + j / g.tiles_m;
-            tile_m = j % g.tiles_m;
+#if BP_WGRAD_NFAST
+            if constexpr (BIASG) {
+                // wgrad: the XCD's few n-panels (dEdX columns) stay hot anyway; walk the m-panels (activation
+                // columns) slowly so the `per` workgroups that share one run back to back and the panel is fetched
+                // into this L2 once, instead of being evicted by the W/delta stream before its next use
+                tile_n = xcd * per + j % per;
+                tile_m = j / per;
+            } else
+#endif
+            {
+                tile_n = xcd * per + j / g.tiles_m;
+                tile_m = j % g.tiles_m;
+            }
         } else {
             tile_m = b % g.tiles_m;
             tile_n = b / g.tiles_m;
