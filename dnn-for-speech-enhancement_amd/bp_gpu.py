@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_dp_forward_layer", "bp_dp_dgrads", "bp_dp_wgrad_layer", "bp_apply_update_layer", "bp_advance_step",
     "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
     "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
+    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info",
 ]
 
 
@@ -111,6 +112,10 @@ def load_library(path=None):
     lib.bp_set_stream.argtypes = [hp, C.c_void_p]
     lib.bp_last_train_ms.argtypes = [hp, fp, C.POINTER(C.c_int)]
     lib.bp_time_kernel.argtypes = [hp, C.c_int, C.c_int, fp]
+    lib.bp_set_hyper.argtypes = [hp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
+    lib.bp_dp_attach.argtypes = [hp, C.c_int, C.c_int, C.c_char_p]
+    lib.bp_dp_detach.argtypes = [hp]
+    lib.bp_dp_info.argtypes = [hp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint)]
     if path is None:
         _lib = lib
     return lib
@@ -185,14 +190,22 @@ class BP_GPU(object):
         return a
 
     # ------------------------------------------------------------------ reference API
+    def _push_hyper(self):
+        """The reference reads its public members afresh on every bunch (BP_GPU.cu:488-500): a caller may
+        assign obj.lrate / momentum / weightcost / dropoutflag / visible_omit / hid_omit between chunks."""
+        self._check(self._lib.bp_set_hyper(self._h, float(self.lrate), float(self.momentum), float(self.weightcost),
+                                           int(self.dropoutflag), float(self.visible_omit), float(self.hid_omit)))
+
     def train(self, n_frames, indata, targ):
         x = self._in(indata, n_frames, self.layersizes[0], "in")
         t = self._in(targ, n_frames, self.layersizes[-1], "targ")
+        self._push_hyper()
         self._check(self._lib.bp_train_chunk(self._h, int(n_frames), _fp(x), _fp(t)))
 
     def CrossValid(self, n_frames, indata, targ):
         x = self._in(indata, n_frames, self.layersizes[0], "in")
         t = self._in(targ, n_frames, self.layersizes[-1], "targ")
+        self._push_hyper()
         e = C.c_float(0.0)
         self._check(self._lib.bp_cv_chunk(self._h, int(n_frames), _fp(x), _fp(t), C.byref(e)))
         return float(e.value)
@@ -326,6 +339,18 @@ class BP_GPU(object):
         o, c = C.c_size_t(), C.c_size_t()
         self._check(self._lib.bp_grad_layout(self._h, int(layer), C.byref(o), C.byref(c)))
         return o.value, c.value
+
+    # ---- in-library data-parallel exchange (bp_dp_attach, include/bp_c_api.h)
+    def dp_attach(self, world, rank, key):
+        self._check(self._lib.bp_dp_attach(self._h, int(world), int(rank), str(key).encode()))
+
+    def dp_detach(self):
+        self._check(self._lib.bp_dp_detach(self._h))
+
+    def dp_info(self):
+        w, r, n = C.c_int(), C.c_int(), C.c_uint()
+        self._check(self._lib.bp_dp_info(self._h, C.byref(w), C.byref(r), C.byref(n)))
+        return int(w.value), int(r.value), int(n.value)
 
     def set_stream(self, hip_stream_ptr):
         self._check(self._lib.bp_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

@@ -156,12 +156,8 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
         float v[4];
         if constexpr (EPI == BEPI_FWD_HIDDEN) {
             uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            if (e.drop_thresh) {                      // same counter layout as the fp32 path (bp_kernels.h)
-                const uint64_t gf = (uint64_t)(uint32_t)(mq + e.frame_off);
-                const uint64_t idx = (gf >> 2) * (uint64_t)(uint32_t)e.n_true + (uint32_t)n;
-                w[0] = (uint32_t)idx; w[1] = (uint32_t)(idx >> 32); w[2] = e.layer; w[3] = e.step;
-                philox4x32_10(w[0], w[1], w[2], w[3], e.seed_lo, e.seed_hi);
-            }
+            // same counter layout as the fp32 path (bp_kernels.h)
+            if (e.drop_thresh) drop_words4(w, mq, n, e.frame_off, (uint32_t)e.n_true, e.layer, e.step, e.seed_lo, e.seed_hi);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float y = act_fwd(e.act, e.alpha * acc[4 * q + j] + bn);

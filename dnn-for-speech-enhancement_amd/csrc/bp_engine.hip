@@ -19,6 +19,14 @@
 #include "../../include/bp_c_api.h"
 #include "bp_kernels.h"
 #include "bp_bf16.h"
+#include "bp_dp.h"
+
+#include <atomic>
+#include <chrono>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -39,7 +47,12 @@ struct bp_handle {
     int cap, chunk_frames;
     hipStream_t own_stream, stream;
     bool grouped;                // all wide wgrad+update problems of a step in one grouped launch
+    // parameters and momentum state live in two flat arenas with the layout of the flat gradient buffer
+    // ([W_1|b_1|W_2|b_2|...], padded; g_off/g_cnt) so that data-parallel ranks can export them as ONE hipIpc
+    // allocation each and the sharded update is a flat elementwise pass (bp_dp.h); W/b/dW/db point into them
+    float *params, *deltas;
     float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
+    struct bp_dp *dp;            // attached data-parallel group (bp_dp_attach) or null
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
     float *in, *in_drop, *targ, *out_dev;
     float *slabs; size_t slab_stride; int out_splits;   // split-K workspace of the output layer
@@ -98,11 +111,13 @@ static int dev_alloc(bp_handle *h, float **p, size_t n_floats)
     return BP_OK;
 }
 
+extern "C" int bp_dp_detach(bp_handle *h);
 extern "C" int bp_destroy(bp_handle *h)
 {
     if (!h) return BP_OK;
     (void)hipSetDevice(h->cfg.device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    if (h->dp) (void)bp_dp_detach(h);
     for (void *p : h->allocs) (void)hipFree(p);
     for (auto &r : h->raw) if (r.p) (void)hipFree(r.p);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
@@ -117,6 +132,11 @@ extern "C" int bp_destroy(bp_handle *h)
     return BP_OK;
 }
 
+extern "C" int bp_dp_detach(bp_handle *h);
+static int dp_check(bp_handle *h);
+static hipError_t dp_bunch(bp_handle *h, int first);
+static hipError_t dp_flush(bp_handle *h);
+static int dp_gather_deltas(bp_handle *h);
 static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs);
 static hipError_t bf_shadow(bp_handle *h, int l);
 
@@ -149,15 +169,11 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0; h->dp_first = 0; h->dp_next_layer = 0; h->dp_fwd_next = 0;
     h->th_vis = cfg->dropoutflag == 1 ? drop_threshold(cfg->visible_omit) : 0u;
     h->th_hid = cfg->dropoutflag == 1 ? drop_threshold(cfg->hid_omit) : 0u;
-    if (cfg->dropoutflag == 1 && (h->B % 4 != 0 || cfg->rank_frame_offset % 4 != 0)) {
-        delete h;
-        return fail(BP_ERR_ARG, "bp_create: dropout needs bunchsize and rank_frame_offset to be multiples of 4");
-    }
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
     h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
     h->grouped = getenv("BP_NO_GROUPED") == nullptr;
     h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
-    h->last_ms = 0.f; h->last_bunches = 0;
+    h->last_ms = 0.f; h->last_bunches = 0; h->dp = nullptr; h->params = h->deltas = nullptr;
 
 #define CK(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_err; bp_destroy(h); g_err = m; return _r; } } while (0)
 #define HK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(_e); bp_destroy(h); return fail(BP_ERR_DEVICE, m); } } while (0)
@@ -187,15 +203,18 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     size_t goff = 0;
     for (int l = 1; l < L; ++l) {
         const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
-        CK(dev_alloc(h, &h->W[l], nw));
-        CK(dev_alloc(h, &h->dW[l], nw));
-        CK(dev_alloc(h, &h->b[l], h->ld[l]));
-        CK(dev_alloc(h, &h->db[l], h->ld[l]));
         CK(dev_alloc(h, &h->y[l], Bp * h->ld[l]));       // rows >= B stay zero (never stored)
         CK(dev_alloc(h, &h->dx[l], Bp * h->ld[l]));      // rows >= B stay zero: k-tail of wgrad
         h->g_off[l] = goff; h->g_cnt[l] = nw + h->ld[l]; goff += h->g_cnt[l];
     }
     h->grad_floats = goff;
+    CK(dev_alloc(h, &h->params, goff));
+    CK(dev_alloc(h, &h->deltas, goff));
+    for (int l = 1; l < L; ++l) {
+        const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
+        h->W[l] = h->params + h->g_off[l]; h->b[l] = h->W[l] + nw;
+        h->dW[l] = h->deltas + h->g_off[l]; h->db[l] = h->dW[l] + nw;
+    }
     if (h->Bg != h->B) CK(dev_alloc(h, &h->grad, goff));   // otherwise allocated on first bp_grads_resident
     for (int l = 1; l < L; ++l) {
         if (!weights[l] || !bias[l]) { bp_destroy(h); return fail(BP_ERR_ARG, "bp_create: weights[l]/bias[l] null"); }
@@ -224,6 +243,25 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     return BP_OK;
 }
 
+extern "C" int bp_set_hyper(bp_handle *h, float lrate, float momentum, float weightcost, int dropoutflag, float visible_omit,
+                            float hid_omit)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    h->cfg.lrate = lrate; h->cfg.momentum = momentum; h->cfg.weightcost = weightcost;
+    if (dropoutflag != h->cfg.dropoutflag || visible_omit != h->cfg.visible_omit || hid_omit != h->cfg.hid_omit) {
+        HIPCHK(hipSetDevice(h->cfg.device));
+        h->cfg.dropoutflag = dropoutflag; h->cfg.visible_omit = visible_omit; h->cfg.hid_omit = hid_omit;
+        h->th_vis = dropoutflag == 1 ? drop_threshold(visible_omit) : 0u;
+        h->th_hid = dropoutflag == 1 ? drop_threshold(hid_omit) : 0u;
+        if (h->th_vis && !h->in_drop) {
+            int r = dev_alloc(h, &h->in_drop, ((size_t)h->cap + 64) * h->ld[0]);
+            if (r != BP_OK) return r;
+        }
+        h->mask_lo = h->mask_hi = -1;
+    }
+    return BP_OK;
+}
+
 extern "C" int bp_set_stream(bp_handle *h, void *hip_stream)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
@@ -238,7 +276,7 @@ extern "C" int bp_sync(bp_handle *h)
     if (!h) return fail(BP_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    return BP_OK;
+    return dp_check(h);
 }
 
 // ------------------------------------------------------------------ launches
@@ -404,10 +442,13 @@ static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const
     return run_wgrads(st, &p, 1, false);
 }
 
+// visible-layer dropout active: bunches read the masked copy of the chunk
+static inline bool use_mask(const bp_handle *h) { return h->in_drop && h->th_vis; }
+
 static hipError_t mask_range(bp_handle *h, int first, int n)
 {
-    if (!h->in_drop || n <= 0) return hipSuccess;
-    dim3 grid((h->ld[0] + 255) / 256, (n + 3) / 4);
+    if (!use_mask(h) || n <= 0) return hipSuccess;
+    dim3 grid((n + 3) / 4, (h->ld[0] + 255) / 256);
     hipLaunchKernelGGL(bp_mask_input, grid, dim3(256), 0, h->stream, h->in, h->in_drop, h->ld[0], h->s[0], first, n,
                        h->B, h->cfg.rank_frame_offset, h->th_vis, (uint32_t)h->cfg.seed,
                        (uint32_t)(h->cfg.seed >> 32), h->step);
@@ -535,7 +576,7 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
     const float *x0 = h->in + (size_t)first * h->ld[0];
-    if (h->in_drop) {
+    if (use_mask(h)) {
         const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
                         (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
                         (first - h->mask_lo) % B == 0;
@@ -708,15 +749,19 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     if (!h) return fail(BP_ERR_ARG, "null handle");
     if (first_frame < 0 || n_frames < 0 || first_frame + n_frames > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_train_resident: frame range outside the resident chunk");
-    if (h->Bg != h->B) return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle, use bp_grads_resident + bp_apply_update");
+    if (h->Bg != h->B && !h->dp)
+        return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle: bp_dp_attach it (in-library exchange) or drive "
+                                  "bp_grads_resident + bp_apply_update yourself");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int nb = n_frames / h->B;          // partial last bunch ignored (BP_GPU.cu:315-318)
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (nb > 0 && h->in_drop) HIPCHK(mask_range(h, first_frame, nb * h->B));
+    if (nb > 0 && use_mask(h)) HIPCHK(mask_range(h, first_frame, nb * h->B));
     for (int i = 0; i < nb; ++i) {
-        HIPCHK(bunch(h, first_frame + i * h->B, true));
+        if (h->dp) HIPCHK(dp_bunch(h, first_frame + i * h->B));
+        else HIPCHK(bunch(h, first_frame + i * h->B, true));
         h->step++;
     }
+    if (h->dp && nb > 0) HIPCHK(dp_flush(h));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_bunches = nb;
     return BP_OK;
@@ -755,7 +800,7 @@ extern "C" int bp_train_chunk_windows(bp_handle *h, const bp_window_chunk *c)
 static hipError_t dp_input(bp_handle *h, int first, const float **x0)
 {
     *x0 = h->in + (size_t)first * h->ld[0];
-    if (h->in_drop) {
+    if (use_mask(h)) {
         const int B = h->B;
         const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
                         (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
@@ -940,6 +985,311 @@ extern "C" int bp_apply_update(bp_handle *h)
     return bp_advance_step(h);
 }
 
+
+// ------------------------------------------------------------------ in-library data-parallel exchange (bp_dp.h)
+// Rendezvous block in POSIX shared memory ("/bpdp-<key>"): hipIpc handles of every rank + a host barrier.
+struct DpShm {
+    std::atomic<uint32_t> magic;
+    std::atomic<int> world;
+    std::atomic<int> bar_count, bar_gen;
+    std::atomic<int> abort_flag;
+    int device[BP_DP_MAXRANKS], pid[BP_DP_MAXRANKS];
+    hipIpcMemHandle_t params[BP_DP_MAXRANKS], grad[BP_DP_MAXRANKS], deltas[BP_DP_MAXRANKS], flags[BP_DP_MAXRANKS];
+};
+struct bp_dp {
+    int world, rank;
+    DpShm *shm; std::string shm_name;
+    float *p_params[BP_DP_MAXRANKS], *p_grad[BP_DP_MAXRANKS], *p_deltas[BP_DP_MAXRANKS];
+    unsigned *p_flags[BP_DP_MAXRANKS];
+    unsigned *flags;              // own flag words (fine-grained device memory, exported)
+    unsigned *arrive;             // [BP_MAXLAYER] last-arriver counters of bp_dp_reduce_update
+    unsigned *err;                // pinned host word the wait kernels raise on timeout
+    hipStream_t comm;             // exchange stream: signal -> wait -> reduce/update/all-gather per layer
+    hipEvent_t ev_g[BP_MAXLAYER]; // main stream: gradient segment l is complete
+    hipEvent_t ev_comm;           // comm stream: everything queued so far is done (flush)
+    unsigned epoch;               // minibatches exchanged so far (flag value of the current one)
+    size_t lo[BP_MAXLAYER], hi[BP_MAXLAYER];   // this rank's slice of layer l's flat segment
+    unsigned long long budget_ticks;
+    bool peers_open;
+};
+
+static int dp_host_barrier(bp_dp *d, double timeout_s)
+{
+    DpShm *s = d->shm;
+    const int gen = s->bar_gen.load();
+    if (s->bar_count.fetch_add(1) + 1 == d->world) { s->bar_count.store(0); s->bar_gen.fetch_add(1); return BP_OK; }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (s->bar_gen.load() == gen) {
+        if (s->abort_flag.load()) return fail(BP_ERR_STATE, "data-parallel group: a peer rank failed");
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+            return fail(BP_ERR_STATE, "data-parallel group: host barrier timed out (a rank is missing)");
+        usleep(100);
+    }
+    return BP_OK;
+}
+
+static double dp_timeout_s()
+{
+    const char *e = getenv("BP_DP_TIMEOUT_S");
+    const double v = e ? atof(e) : 60.0;
+    return v > 0.5 ? v : 0.5;
+}
+
+static void dp_release(bp_handle *h)
+{
+    bp_dp *d = h->dp;
+    if (!d) return;
+    if (d->comm) (void)hipStreamSynchronize(d->comm);
+    if (d->peers_open)
+        for (int p = 0; p < d->world; ++p) {
+            if (p == d->rank) continue;
+            if (d->p_params[p]) (void)hipIpcCloseMemHandle(d->p_params[p]);
+            if (d->p_grad[p]) (void)hipIpcCloseMemHandle(d->p_grad[p]);
+            if (d->p_deltas[p]) (void)hipIpcCloseMemHandle(d->p_deltas[p]);
+            if (d->p_flags[p]) (void)hipIpcCloseMemHandle(d->p_flags[p]);
+        }
+    for (auto &e : d->ev_g) if (e) (void)hipEventDestroy(e);
+    if (d->ev_comm) (void)hipEventDestroy(d->ev_comm);
+    if (d->comm) (void)hipStreamDestroy(d->comm);
+    if (d->flags) (void)hipFree(d->flags);
+    if (d->arrive) (void)hipFree(d->arrive);
+    if (d->err) (void)hipHostFree(d->err);
+    if (d->shm) munmap((void *)d->shm, sizeof(DpShm));
+    if (d->rank == 0 && !d->shm_name.empty()) shm_unlink(d->shm_name.c_str());
+    delete d;
+    h->dp = nullptr;
+}
+
+extern "C" int bp_dp_detach(bp_handle *h)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (!h->dp) return BP_OK;
+    (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    bp_dp *d = h->dp;
+    // nobody may unmap a buffer a peer kernel could still touch: everyone arrives here quiescent first
+    int r = d->peers_open ? dp_host_barrier(d, dp_timeout_s()) : BP_OK;
+    dp_release(h);
+    return r;
+}
+
+extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
+{
+    if (!h || !key || !*key) return fail(BP_ERR_ARG, "bp_dp_attach: null argument");
+    if (world < 1 || world > BP_DP_MAXRANKS || rank < 0 || rank >= world)
+        return fail(BP_ERR_ARG, "bp_dp_attach: world must be 1..8 and 0 <= rank < world");
+    if (h->dp) return fail(BP_ERR_STATE, "bp_dp_attach: handle is already attached");
+    if (h->Bg != h->B * world || h->cfg.rank_frame_offset != rank * h->B)
+        return fail(BP_ERR_ARG, "bp_dp_attach: create the handle with global_bunchsize = world*bunchsize and rank_frame_offset = rank*bunchsize");
+    if (h->L - 1 >= 16) return fail(BP_ERR_ARG, "bp_dp_attach: too many layers");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    bp_dp *d = new bp_dp();
+    h->dp = d;
+    d->world = world; d->rank = rank; d->epoch = 0; d->peers_open = false;
+    d->budget_ticks = (unsigned long long)(dp_timeout_s() * 1.0e8);      // wall_clock64: 100 MHz
+#define DK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string("bp_dp_attach: ") + #x + ": " + hipGetErrorString(_e); \
+        if (d->shm) d->shm->abort_flag.store(1); dp_release(h); return fail(BP_ERR_DEVICE, m); } } while (0)
+    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) { dp_release(h); return r; } }
+    DK(hipExtMallocWithFlags((void **)&d->flags, BP_DP_FLAG_WORDS * sizeof(unsigned), hipDeviceMallocFinegrained));
+    DK(hipMemset(d->flags, 0, BP_DP_FLAG_WORDS * sizeof(unsigned)));
+    DK(hipMalloc((void **)&d->arrive, BP_MAXLAYER * sizeof(unsigned)));
+    DK(hipMemset(d->arrive, 0, BP_MAXLAYER * sizeof(unsigned)));
+    DK(hipHostMalloc((void **)&d->err, sizeof(unsigned), hipHostMallocMapped));
+    *d->err = 0u;
+    DK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+    for (int l = 1; l < h->L; ++l) DK(hipEventCreateWithFlags(&d->ev_g[l], hipEventDisableTiming));
+    DK(hipEventCreateWithFlags(&d->ev_comm, hipEventDisableTiming));
+    DK(hipStreamSynchronize(h->stream));
+    for (int l = 1; l < h->L; ++l) {                           // equal float4-aligned slices of [W_l|b_l]
+        const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + world - 1) / world;
+        const size_t a = per4 * rank < cnt4 ? per4 * rank : cnt4, b = per4 * (rank + 1) < cnt4 ? per4 * (rank + 1) : cnt4;
+        d->lo[l] = h->g_off[l] + 4 * a; d->hi[l] = h->g_off[l] + 4 * b;
+    }
+    // ---- rendezvous
+    d->shm_name = std::string("/bpdp-") + key;
+    const int fd = shm_open(d->shm_name.c_str(), O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(DpShm)) != 0) {
+        if (fd >= 0) close(fd);
+        dp_release(h);
+        return fail(BP_ERR_STATE, "bp_dp_attach: cannot create the shared rendezvous block " + std::string("/bpdp-") + key);
+    }
+    d->shm = (DpShm *)mmap(nullptr, sizeof(DpShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (d->shm == MAP_FAILED) { d->shm = nullptr; dp_release(h); return fail(BP_ERR_STATE, "bp_dp_attach: mmap of the rendezvous block failed"); }
+    DpShm *s = d->shm;
+    int w0 = 0;
+    if (!s->world.compare_exchange_strong(w0, world) && w0 != world) {
+        dp_release(h);
+        return fail(BP_ERR_ARG, "bp_dp_attach: ranks disagree on the world size (or a stale rendezvous block with this key exists)");
+    }
+    s->device[rank] = h->cfg.device; s->pid[rank] = (int)getpid();
+    DK(hipIpcGetMemHandle(&s->params[rank], h->params));
+    DK(hipIpcGetMemHandle(&s->grad[rank], h->grad));
+    DK(hipIpcGetMemHandle(&s->deltas[rank], h->deltas));
+    DK(hipIpcGetMemHandle(&s->flags[rank], d->flags));
+    int r = dp_host_barrier(d, dp_timeout_s());
+    if (r != BP_OK) { std::string m = g_err; dp_release(h); g_err = m; return r; }
+    d->peers_open = true;
+    for (int p = 0; p < world; ++p) {
+        if (p == rank) { d->p_params[p] = h->params; d->p_grad[p] = h->grad; d->p_deltas[p] = h->deltas; d->p_flags[p] = d->flags; continue; }
+        DK(hipIpcOpenMemHandle((void **)&d->p_params[p], s->params[p], hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_grad[p], s->grad[p], hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_deltas[p], s->deltas[p], hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_flags[p], s->flags[p], hipIpcMemLazyEnablePeerAccess));
+    }
+#undef DK
+    r = dp_host_barrier(d, dp_timeout_s());                    // every rank has mapped every peer
+    if (r != BP_OK) { std::string m = g_err; dp_release(h); g_err = m; return r; }
+    return BP_OK;
+}
+
+static int dp_check(bp_handle *h)
+{
+    if (h->dp && *(volatile unsigned *)h->dp->err) {
+        const unsigned e = *(volatile unsigned *)h->dp->err;
+        return fail(BP_ERR_STATE, "data-parallel exchange timed out on the device: waiting for rank " + std::to_string((e % 1000u) - 1u) +
+                                      (e / 1000u == 1 ? " (gradient ready)" : " (weights gathered)"));
+    }
+    return BP_OK;
+}
+
+static DpPeers dp_peers(const bp_dp *d)
+{
+    DpPeers p; memset(&p, 0, sizeof(p));
+    for (int i = 0; i < d->world; ++i) p.flags[i] = d->p_flags[i];
+    return p;
+}
+
+// main stream: the weights of layer l gathered from every rank for minibatch `epoch` (none before the first)
+static hipError_t dp_wait_weights(bp_handle *h, int l, unsigned epoch)
+{
+    bp_dp *d = h->dp;
+    if (epoch == 0) return hipSuccess;
+    hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, h->stream, d->flags, bp_dp_flag_index(BP_DP_FLAG_W, l, 0), d->world, epoch,
+                       d->budget_ticks, d->err, 2u);
+    return hipGetLastError();
+}
+
+// comm stream, after the gradient segment of layer l is complete on the main stream: tell every rank, wait for
+// every rank's segment, then reduce this rank's slice, update it and write the new weights to every rank
+static hipError_t dp_exchange_layer(bp_handle *h, int l)
+{
+    bp_dp *d = h->dp;
+    hipError_t er;
+    if ((er = hipEventRecord(d->ev_g[l], h->stream)) != hipSuccess) return er;
+    if ((er = hipStreamWaitEvent(d->comm, d->ev_g[l], 0)) != hipSuccess) return er;
+    const DpPeers peers = dp_peers(d);
+    hipLaunchKernelGGL(bp_dp_signal, dim3(1), dim3(64), 0, d->comm, peers, d->world, bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), d->epoch);
+    hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, d->comm, d->flags, bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->world, d->epoch,
+                       d->budget_ticks, d->err, 1u);
+    DpReduceArgs a; memset(&a, 0, sizeof(a));
+    for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
+    a.delta = h->deltas; a.lo = d->lo[l]; a.hi = d->hi[l];
+    a.w_end = h->g_off[l] + (size_t)h->ld[l - 1] * h->ld[l];
+    a.world = d->world; a.rank = d->rank;
+    const float m = h->cfg.momentum, lr = h->cfg.lrate;
+    a.mom = m; a.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; a.wc = h->cfg.weightcost; a.ndiv = (float)h->Bg;
+    a.arrive = d->arrive + l; a.peers = peers; a.flag_index = bp_dp_flag_index(BP_DP_FLAG_W, l, d->rank); a.epoch = d->epoch;
+    const size_t n4 = (a.hi - a.lo) / 4;
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;                                    // (an empty slice still raises its flag)
+    switch (d->world) {
+    case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    case 4: hipLaunchKernelGGL(bp_dp_reduce_update<4>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    case 8: hipLaunchKernelGGL(bp_dp_reduce_update<8>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    default: hipLaunchKernelGGL(bp_dp_reduce_update<0>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    }
+    return hipGetLastError();
+}
+
+// One data-parallel minibatch (this rank's shard starts at chunk frame `first`).  Per layer: wait for the gathered
+// weights of the previous minibatch right before the layer's forward; after all dgrads the weight gradients go out
+// largest segment first, each followed at once by its exchange on the comm stream -- so the exchange of layer l
+// overlaps the remaining weight gradients and the NEXT minibatch's forward of the layers before l.
+static hipError_t dp_bunch(bp_handle *h, int first)
+{
+    bp_dp *d = h->dp;
+    const int L = h->L, B = h->B;
+    hipError_t er;
+#define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
+    const float *x0;
+    CKE(dp_input(h, first, &x0));
+    const float *tg = h->targ + (size_t)first * h->ld[L - 1];
+    const unsigned prev_epoch = d->epoch;
+    d->epoch++;
+    if (h->bf) {
+        for (int l = 1; l < L; ++l) {
+            CKE(dp_wait_weights(h, l, prev_epoch));
+            if (prev_epoch) CKE(bf_shadow(h, l));               // bf16 copies of the gathered fp32 weights
+            if (l == 1) CKE(bf_input(h, x0, B));
+            CKE(bf_fwd(h, l, B, tg, nullptr, true, 1.0f));
+        }
+        for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));
+        for (int l = 1; l < L; ++l) { CKE(bf_wgrad(h, l, false)); CKE(dp_exchange_layer(h, l)); }
+    } else {
+        for (int l = 1; l < L; ++l) {
+            CKE(dp_wait_weights(h, l, prev_epoch));
+            CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
+        }
+        for (int l = L - 1; l >= 2; --l) CKE(launch_dgrad(h, h->stream, l, B));
+        for (int l = 1; l < L; ++l) {
+            CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], false));
+            CKE(dp_exchange_layer(h, l));
+        }
+    }
+#undef CKE
+    return hipSuccess;
+}
+
+// After the last minibatch of a call: the main stream waits until every layer's weights have been gathered (and
+// therefore every peer has finished reading this rank's gradients), so that stream order again covers everything.
+static hipError_t dp_flush(bp_handle *h)
+{
+    bp_dp *d = h->dp;
+    hipError_t er;
+    for (int l = 1; l < h->L; ++l) {
+        if ((er = dp_wait_weights(h, l, d->epoch)) != hipSuccess) return er;
+        if (h->bf && d->epoch && (er = bf_shadow(h, l)) != hipSuccess) return er;
+    }
+    if ((er = hipEventRecord(d->ev_comm, d->comm)) != hipSuccess) return er;
+    return hipStreamWaitEvent(h->stream, d->ev_comm, 0);
+}
+
+// bp_get_deltas on an attached handle: the momentum state is sharded; pull the peers' slices into the local arena.
+static int dp_gather_deltas(bp_handle *h)
+{
+    bp_dp *d = h->dp;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int r = dp_host_barrier(d, dp_timeout_s());                // every rank quiescent: slices are final
+    if (r != BP_OK) return r;
+    for (int l = 1; l < h->L; ++l) {
+        const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + d->world - 1) / d->world;
+        for (int p = 0; p < d->world; ++p) {
+            if (p == d->rank) continue;
+            const size_t a = per4 * p < cnt4 ? per4 * p : cnt4, b = per4 * (p + 1) < cnt4 ? per4 * (p + 1) : cnt4;
+            if (b <= a) continue;
+            const size_t off = h->g_off[l] + 4 * a;
+            int grid = (int)((b - a + 255) / 256); if (grid > 1024) grid = 1024;
+            hipLaunchKernelGGL(bp_dp_copy, dim3(grid), dim3(256), 0, h->stream, h->deltas + off, d->p_deltas[p] + off, (unsigned long long)(b - a));
+            HIPCHK(hipGetLastError());
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return dp_host_barrier(d, dp_timeout_s());                 // nobody resumes training while a peer still reads
+}
+
+extern "C" int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibatches)
+{
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (world) *world = h->dp ? h->dp->world : 0;
+    if (rank) *rank = h->dp ? h->dp->rank : 0;
+    if (minibatches) *minibatches = h->dp ? h->dp->epoch : 0;
+    return BP_OK;
+}
+
 // ------------------------------------------------------------------ inference / CV
 static int forward_bunch(bp_handle *h, int first, int fb)
 {
@@ -1029,6 +1379,7 @@ static int get_params(bp_handle *h, float *const *w, float *const *b, bool delta
 {
     if (!h || !w || !b) return fail(BP_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (deltas && h->dp && h->dp->world > 1) { int r = dp_gather_deltas(h); if (r != BP_OK) return r; }
     for (int l = 1; l < h->L; ++l) {
         if (!w[l] || !b[l]) return fail(BP_ERR_ARG, "weights[l]/bias[l] null");
         HIPCHK(hipMemcpy2DAsync(w[l], (size_t)h->s[l] * 4, deltas ? h->dW[l] : h->W[l], (size_t)h->ld[l] * 4,
@@ -1036,7 +1387,7 @@ static int get_params(bp_handle *h, float *const *w, float *const *b, bool delta
         HIPCHK(hipMemcpyAsync(b[l], deltas ? h->db[l] : h->b[l], (size_t)h->s[l] * 4, hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));    // reference relies on pageable-copy semantics (BP_GPU.cu:920-921)
-    return BP_OK;
+    return dp_check(h);
 }
 extern "C" int bp_get_weights(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, false); }
 extern "C" int bp_get_deltas(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, true); }

@@ -86,6 +86,26 @@ __device__ __forceinline__ void philox4x32_10(uint32_t &c0, uint32_t &c1, uint32
     }
 }
 
+// Dropout words of the 4 consecutive bunch rows r0..r0+3 (r0 % 4 == 0) of unit n: word (gf & 3) of the Philox block
+// keyed by (gf >> 2, unit) with gf = global frame index = row + frame_off.  frame_off % 4 == 0 (the usual case) needs
+// one block; otherwise the four rows straddle two (frame_off is a launch constant, so the branch is uniform).
+__device__ __forceinline__ void drop_words4(uint32_t (&w)[4], int r0, int n, int frame_off, uint32_t n_true, uint32_t layer,
+                                            uint32_t step, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const uint64_t g0 = (uint64_t)(uint32_t)(r0 + frame_off);
+    const uint64_t idx = (g0 >> 2) * (uint64_t)n_true + (uint32_t)n;
+    uint32_t a[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), layer, step};
+    philox4x32_10(a[0], a[1], a[2], a[3], seed_lo, seed_hi);
+    const int sh = frame_off & 3;
+    if (sh == 0) { w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; return; }
+    const uint64_t idx2 = idx + (uint64_t)n_true;
+    uint32_t b[4] = {(uint32_t)idx2, (uint32_t)(idx2 >> 32), layer, step};
+    philox4x32_10(b[0], b[1], b[2], b[3], seed_lo, seed_hi);
+    if (sh == 1) { w[0] = a[1]; w[1] = a[2]; w[2] = a[3]; w[3] = b[0]; }
+    else if (sh == 2) { w[0] = a[2]; w[1] = a[3]; w[2] = b[0]; w[3] = b[1]; }
+    else { w[0] = a[3]; w[1] = b[0]; w[2] = b[1]; w[3] = b[2]; }
+}
+
 __device__ __forceinline__ float act_fwd(int act, float x)
 {
     // DevFunc.cu:67-79 (ReLU, strict > 0) | DevFunc.cu:47-54 (.bak: 1/(1+expf(-x)))
@@ -274,12 +294,7 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
         for (int q = R0 / 4; q < (R0 + RN) / 4; ++q) {
             uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             const int r0 = rbase + 8 * q;
-            if (e.drop_thresh) {
-                const uint64_t gf = (uint64_t)(uint32_t)(r0 + e.frame_off);
-                const uint64_t idx = (gf >> 2) * (uint64_t)(uint32_t)e.n_true + (uint32_t)n;
-                w[0] = (uint32_t)idx; w[1] = (uint32_t)(idx >> 32); w[2] = e.layer; w[3] = e.step;
-                philox4x32_10(w[0], w[1], w[2], w[3], e.seed_lo, e.seed_hi);
-            }
+            if (e.drop_thresh) drop_words4(w, r0, n, e.frame_off, (uint32_t)e.n_true, e.layer, e.step, e.seed_lo, e.seed_hi);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int m = r0 + j;
@@ -918,8 +933,8 @@ __global__ void bp_mask_input(const float *in, float *out, int ld, int width, in
                               int bunch, int frame_off, uint32_t thresh, uint32_t seed_lo, uint32_t seed_hi,
                               uint32_t step0)
 {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    const int g4 = blockIdx.y;
+    const int u = blockIdx.y * blockDim.x + threadIdx.x;     // unit blocks on grid.y (few), frame groups on grid.x (many)
+    const int g4 = blockIdx.x;
     if (u >= ld) return;
     uint32_t w[4]; uint64_t cur_blk = ~0ull; uint32_t cur_step = 0;
     for (int j = 0; j < 4; ++j) {

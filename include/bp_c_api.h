@@ -87,6 +87,13 @@ int bp_create(const bp_config *cfg, const float *const *weights, const float *co
 /* BP_GPU::~BP_GPU (BP_GPU.cu:199-239). */
 int bp_destroy(bp_handle *h);
 
+/* The reference reads its public members lrate / momentum / weightcost / dropoutflag / visible_omit /
+ * hid_omit afresh on every bunch (train_bunch_single: `cur_lrate = lrate`, BP_GPU.cu:488-500), so a caller
+ * may change them between chunks.  This pushes new values into the handle; the C++ shim calls it at the
+ * start of train() and CrossValid() with the current member values. */
+int bp_set_hyper(bp_handle *h, float lrate, float momentum, float weightcost, int dropoutflag,
+                 float visible_omit, float hid_omit);
+
 /* BP_GPU::train (BP_GPU.cu:241-331): upload a chunk of n_frames stacked input frames and
  * targets, then run one SGD-momentum step (train_bunch_single, BP_GPU.cu:484-673) per
  * consecutive full bunch; the partial last bunch is ignored (:315-318).  Synchronous with
@@ -190,6 +197,26 @@ int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *count);
 /* Run the device work of this handle on an externally owned hipStream_t (passed as void*),
  * e.g. the stream a communication library orders against.  NULL restores the private stream. */
 int bp_set_stream(bp_handle *h, void *hip_stream);
+
+/* ------------------------------------------------------------------------------------
+ * In-library data-parallel exchange.  One process per GPU; each rank creates its handle
+ * with bunchsize = frames of a minibatch it owns, global_bunchsize = world * bunchsize and
+ * rank_frame_offset = rank * bunchsize, then joins the group.  `key` names the job (every rank passes the
+ * same string, unique per job on the machine; a POSIX shared-memory block "/bpdp-<key>" carries the
+ * rendezvous).  After bp_dp_attach, bp_train_resident / bp_train_chunk / bp_train_chunk_windows run
+ * the data-parallel step on this rank's shard of every minibatch: per layer reduce-scatter of the
+ * gradients (peer reads over xGMI through hipIpc mappings), momentum update of this rank's 1/world slice
+ * of W and delta, all-gather of the new W (peer writes), ordered by device-side flags -- the semantics of
+ * the reference's commented-out train_bunch_multi (BP_GPU.cu:775-908: gradient SUM, one update with
+ * n = global bunch, identical weights everywhere) without routing through GPU 0.  No collective library
+ * and no host synchronisation on the data path.  Every rank must make the same sequence of training
+ * calls with the same number of minibatches.  Ranks may share a device (functional testing).
+ * bp_get_weights works on every rank (weights are replicated); bp_get_deltas gathers the sharded momentum
+ * state and must be called by all ranks together.  A rank that stops responding makes the others fail
+ * with BP_ERR_STATE after BP_DP_TIMEOUT_S seconds (default 60) instead of hanging. */
+int bp_dp_attach(bp_handle *h, int world, int rank, const char *key);
+int bp_dp_detach(bp_handle *h);     /* collective; also done by bp_destroy */
+int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibatches);
 
 /* Timing of the dominant kernels for roofline reporting: average duration (ms) of the last
  * bp_train_resident call's whole bunch loop measured with HIP events on the handle's stream. */
