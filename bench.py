@@ -8,9 +8,15 @@ Workload at every N (weak scaling, per-GPU work fixed): BASELINE.json configs[1]
 2827->2048->2048->2048->257 (257x11 stacked input), ReLU + dropout 0.1/0.2, fp32, 256 frames
 per GPU per step, lrate 1, momentum 0.5, synthetic N(0,1) frames resident in HBM (generated on
 device), Glorot*0.5 weights.  A step = forward + backward + momentum update of one bunch
-(train_bunch_single, BP_GPU.cu:484-673); for N>1 the global bunch is N*256 frames with one
-RCCL all-reduce(SUM) of the gradients per step.
-Prints ONE JSON line on rank 0.
+(train_bunch_single, BP_GPU.cu:484-673).  For N>1 the global bunch is N*256 frames and the
+gradient exchange is the LIBRARY's own (bp_dp_attach: hipIpc peer reduce-scatter + sharded fused
+update + all-gather, include/bp_c_api.h) -- torch.distributed (gloo) only provides the barrier
+around the timed region and the max over ranks.
+
+Timing protocol: `prewarm_s` seconds of real, untimed training steps first (a freshly leased GPU
+needs that long to reach its sustained clocks; reported in the line), then W untimed warm-up
+steps, then EXACTLY K timed steps between barrier+synchronize pairs.  Nothing is skipped in the
+timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -20,20 +26,29 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: needed by RCCL across processes on this driver
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: needed for hipIpc across processes on this driver
 
 import numpy as np  # noqa: E402
 
 LAYERS = [257 * 11, 2048, 2048, 2048, 257]
 BUNCH = 256
 CHUNK = 102400            # frames resident per chunk (finetune_..._NAT.pl:39 traincache)
-PEAK_MFMA_F32_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_F32_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec, 2.4 GHz)
+PEAK_HBM_GBS = 8000.0     # spec
+C5_LAYERS = [257 * 11, 4096, 4096, 4096, 4096, 4096, 257]   # BASELINE.json configs[4], per-GPU shard of 512 frames
+C5_BUNCH = 512
+
+
+def n_params(ls):
+    return sum(ls[i - 1] * ls[i] for i in range(1, len(ls)))
 
 
 def flops_per_frame(ls):
-    P = sum(ls[i - 1] * ls[i] for i in range(1, len(ls)))
-    return 6 * P - 2 * ls[0] * ls[1]
+    return 6 * n_params(ls) - 2 * ls[0] * ls[1]
+
+
+def wgrad_flops_per_step(ls, B):
+    return 2.0 * B * n_params(ls)
 
 
 def cpu_baseline(W, b, budget_s=12.0, max_steps=64):
@@ -52,9 +67,78 @@ def cpu_baseline(W, b, budget_s=12.0, max_steps=64):
         n += 1
     dt = time.perf_counter() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": n * BUNCH / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d full C2 training steps (256 frames each, fp32, dropout on) of oracle/bp_oracle.c "
-                      "(OpenMP, %d threads), %.1f s" % (n, cores, dt)}
+    res = {"value": n * BUNCH / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d full C2 training steps (256 frames each, fp32, dropout on) of oracle/bp_oracle.c "
+                     "(OpenMP, %d threads), %.1f s" % (n, cores, dt)}
+    try:
+        res["torch_cpu_not_the_reference"] = torch_cpu_line(W, b, budget_s=min(6.0, budget_s / 2))
+    except Exception as e:                   # a labelled extra, never fatal
+        res["torch_cpu_not_the_reference"] = {"error": str(e)[:200]}
+    return res
+
+
+def torch_cpu_line(W, b, budget_s=6.0):
+    """Same C2 step written with torch CPU ops (vendor BLAS under torch.mm): NOT the reference and not
+    the oracle -- a labelled second opinion on what this box's host cores can do with a tuned SGEMM."""
+    import torch
+    Ws = [None] + [torch.from_numpy(np.ascontiguousarray(W[l])) for l in range(1, len(LAYERS))]
+    bs = [None] + [torch.from_numpy(np.ascontiguousarray(b[l])) for l in range(1, len(LAYERS))]
+    dW = [None] + [torch.zeros_like(w) for w in Ws[1:]]
+    db = [None] + [torch.zeros_like(v) for v in bs[1:]]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(BUNCH, LAYERS[0], generator=g)
+    t = torch.randn(BUNCH, LAYERS[-1], generator=g)
+    L, m, lr = len(LAYERS), 0.5, 1.0
+
+    def step():
+        ys = [x * (torch.rand(x.shape, generator=g) >= 0.1)]
+        for l in range(1, L):
+            z = torch.addmm(bs[l], ys[-1], Ws[l])
+            ys.append(torch.relu(z) * (torch.rand(z.shape, generator=g) >= 0.2) if l < L - 1 else z)
+        dx = (2.0 / BUNCH) * (ys[-1] - t)
+        for l in range(L - 1, 0, -1):
+            dprev = (dx @ Ws[l].t()) * (ys[l - 1] > 0) if l > 1 else None
+            G = ys[l - 1].t() @ dx
+            dW[l].mul_(m).sub_((1 - m) * lr * (G / BUNCH)); Ws[l].add_(dW[l])
+            db[l].mul_(m).sub_((1 - m) * lr * (dx.sum(0) / BUNCH)); bs[l].add_(db[l])
+            dx = dprev
+    step()
+    n, t0 = 0, time.perf_counter()
+    while n < 200 and time.perf_counter() - t0 < budget_s:
+        step(); n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * BUNCH / dt, "unit": "frames/s", "threads": torch.get_num_threads(),
+            "sample": "%d C2 steps with torch CPU ops, %.1f s" % (n, dt)}
+
+
+def c5_line(dnnse_amd, dev, steps=40):
+    """BASELINE.json configs[4] per-GPU shape (2827->4096x5->257, 512 frames per GPU, bf16 operands, fp32
+    master weights) on this one GPU: step time and its HBM roofline (the step is HBM-bound)."""
+    W, b = dnnse_amd.glorot_net(C5_LAYERS, seed=1, beta=0.5)
+    g = dnnse_amd.BP_GPU(1, len(C5_LAYERS), C5_LAYERS, C5_BUNCH, 1.0, 0.5, 0.0, W, b, device=dev,
+                         max_chunk_frames=16 * C5_BUNCH, compute_dtype=1)
+    g.fill_chunk_synthetic(16 * C5_BUNCH, 20260927)
+    for _ in range(3):
+        g.train_resident(0, 16 * C5_BUNCH)
+    g.sync()
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps:
+        k = min(16, steps - done)
+        g.train_resident(0, k * C5_BUNCH)
+        done += k
+    g.sync()
+    dt = (time.perf_counter() - t0) / steps
+    g.close()
+    P = n_params(C5_LAYERS)
+    # algorithmic bytes per step of the bf16 mode (SURVEY 8d, lower figure): bf16 weights read by fwd and dgrad
+    # (2P + 2(P - s0 s1)), fp32 W and delta read + written by the fused update (16P), bf16 shadow refresh (2P)
+    alg = 22.0 * P - 2.0 * C5_LAYERS[0] * C5_LAYERS[1]
+    return {"workload": "configs[4] per-GPU shape: 2827->4096x5->257, 512 frames/GPU/step, bf16 operands, fp32 master W/delta, 1 GPU",
+            "dtype": "bf16", "ms_per_step": 1e3 * dt, "value": C5_BUNCH / dt, "unit": "frames/s",
+            "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_step": alg, "traffic": None},
+            "frac_of_bf16_mfma_peak": flops_per_frame(C5_LAYERS) * C5_BUNCH / dt / 2.5e15}
 
 
 def main():
@@ -62,7 +146,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--prewarm-s", type=float, default=1.5, help="seconds of real untimed training steps before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C5 line and the measured peaks")
     ap.add_argument("--chunk", type=int, default=CHUNK)
     args = ap.parse_args()
 
@@ -73,80 +159,68 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    force_dp = os.environ.get("BENCH_FORCE_DP") == "1"      # exercise the data-parallel path at world size 1
-    if world > 1 or force_dp:
+    force_dp = os.environ.get("BENCH_FORCE_DP") == "1"      # exercise the exchange path at world size 1
+    if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+        dist.init_process_group(backend="gloo")             # barrier + max over ranks only; the exchange is the library's
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
-    dev = local_rank
+    ndev = torch.cuda.device_count()
+    dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev)
 
     W, b = dnnse_amd.glorot_net(LAYERS, seed=1, beta=0.5)    # Gen_rand_net flag=1, beta=0.5 recipe
     chunk = max(BUNCH, (args.chunk // BUNCH) * BUNCH)
     kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=20260927, device=dev, max_chunk_frames=chunk)
+    dp = world > 1 or force_dp
+    if dp:
+        kw.update(global_bunchsize=BUNCH * world, rank_frame_offset=rank * BUNCH)
+    g = dnnse_amd.BP_GPU(world, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, **kw)
+    if dp:
+        key = "bench-%s-%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
+        g.dp_attach(world, rank, key)
+    g.fill_chunk_synthetic(chunk, 20260927 + rank)            # each rank holds its own shard of every bunch
+    g.sync()
+    nb_chunk = chunk // BUNCH
 
     def barrier():
+        g.sync()
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
 
-    if world == 1 and not force_dp:
-        g = dnnse_amd.BP_GPU(1, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, **kw)
-        g.fill_chunk_synthetic(chunk, 20260927)
-        g.sync()
-        nb_chunk = chunk // BUNCH
+    def run(nsteps, pos):
+        done = 0
+        while done < nsteps:
+            k = min(nsteps - done, nb_chunk - pos)
+            g.train_resident(pos * BUNCH, k * BUNCH)
+            done += k
+            pos = (pos + k) % nb_chunk
+        return pos
 
-        def run(nsteps, pos):
-            done = 0
-            while done < nsteps:
-                k = min(nsteps - done, nb_chunk - pos)
-                g.train_resident(pos * BUNCH, k * BUNCH)
-                done += k
-                pos = (pos + k) % nb_chunk
-            return pos
-
-        pos = run(args.warmup, 0)
-        g.sync(); barrier()
-        t0 = time.perf_counter()
-        pos = run(args.steps, pos)
-        g.sync(); barrier()
-        dt = time.perf_counter() - t0
-        obj = g
-    else:
-        from importlib import import_module
-        dp = import_module("dnn_for_speech_enhancement_amd.dp")
-        eng = dp.HipEngine(dnnse_amd, LAYERS, BUNCH, world, rank, 1.0, 0.5, 0.0, W, b, **kw)
-        eng.obj.fill_chunk_synthetic(chunk, 20260927 + rank)       # each rank holds its own shard of every bunch
-        nb_chunk = chunk // BUNCH
-        pos = 0
-        mode = os.environ.get("BENCH_DP_MODE", "pipeline")     # pipeline | overlapped | serial
-        if mode == "pipeline":
-            pipe = dp.DPPipeline(eng, dist)
-            step_fn = lambda e, d, f: pipe.step(f)
-            flush = pipe.flush
-        else:
-            step_fn = dp.dp_step if mode == "serial" else dp.dp_step_overlapped
-            flush = lambda: None
-        for _ in range(args.warmup):
-            step_fn(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
-        flush()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step_fn(eng, dist, pos * BUNCH); pos = (pos + 1) % nb_chunk
-        flush()
-        barrier()
-        dt = time.perf_counter() - t0
-        obj = eng.obj
+    # ---- untimed pre-warm: real steps, same work as the timed region (every rank the same count)
+    pos, prewarm_steps, t0 = 0, 0, time.perf_counter()
+    if args.prewarm_s > 0:
+        pos = run(200, pos); g.sync(); prewarm_steps = 200
+        per = (time.perf_counter() - t0) / 200
+        extra = int(max(0.0, args.prewarm_s - (time.perf_counter() - t0)) / per)
+        if dist is not None:                                  # same number of exchanges on every rank
+            tt = torch.tensor([extra], dtype=torch.int64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            extra = int(tt.item())
+        if extra > 0:
+            pos = run(extra, pos); g.sync(); prewarm_steps += extra
+    prewarm_s = time.perf_counter() - t0
+    pos = run(args.warmup, pos)
+    barrier()
+    t0 = time.perf_counter()
+    pos = run(args.steps, pos)
+    barrier()
+    dt = time.perf_counter() - t0
 
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -156,44 +230,77 @@ def main():
         "metric": "training frames/sec (257x11 input, 3x2048 DNN)", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "prewarm_s": prewarm_s, "prewarm_steps": prewarm_steps,
         "config": {"workload": "C2: 2827->2048->2048->2048->257 ReLU+dropout(0.1/0.2), fp32, %d frames/GPU/step "
                                "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
                                % (BUNCH, BUNCH * world, chunk),
-                   "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world},
+                   "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world,
+                   "exchange": ("in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)" if dp else "none")},
     }
     if rank == 0:
-        # ---- roofline of the dominant kernel: the 2048x2048 hidden-layer forward GEMM
-        # (M=256 frames, N=K=2048): algorithmic FLOPs = 2*M*N*K per launch, duration = HIP events
-        # around `iters` back-to-back launches on the kernel's own stream (bp_time_kernel).
-        it = 200
-        ms = {name: obj.time_kernel(k, it) for name, k in
-              (("fwd_hidden", 0), ("dgrad_hidden", 1), ("wgrad_update_hidden", 2), ("fwd_l1", 3), ("fwd_out", 4),
-               ("wgrad_update_l1", 5))}
-        fl = 2.0 * BUNCH * 2048 * 2048
-        ach = fl / (ms["fwd_hidden"] * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate
-        # FETCH_SIZE / WRITE_SIZE runs of this same command, KB units, FETCH doubled per the gfx950
-        # note in MI355X_MICROARCH.md): profiles/r01_pmc_hbm_traffic.json.  null when absent.
-        traffic = None
+        res["step_frac_of_mfma_peak"] = flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF
+    if dp:
+        g.dp_detach()
+    if rank == 0 and not dp:
+        # ---- roofline of the TIME-DOMINANT kernel: the grouped wgrad + fused momentum update of all layers
+        # (bp_gemm_multi<GemmKernel<64,64,32,2,2,false,false,EPI_WGRAD_UPDATE,1,8>>, one launch per step, ~38 % of the
+        # step).  achieved = algorithmic FLOPs per launch (2*B*P: every layer's G = y^T.dEdX) / its average duration
+        # INSIDE the step, measured live with HIP events on the launch stream (bp_profile_step: an event after every
+        # launch of 100 real training steps).  The rocprofv3 --kernel-trace --stats summary of this same command is
+        # committed under profiles/ (its average for that kernel is the cross-check).
+        prof = g.profile_step(0, 100)
+        wg_ms = prof["wgrad_update_grouped"][0]
+        wg_fl = wgrad_flops_per_step(LAYERS, BUNCH)
+        ach = wg_fl / (wg_ms * 1e-3) / 1e12
+        P = n_params(LAYERS)
+        # algorithmic bytes of that launch: W and delta read + written (16P) + every layer's activations and dEdX read once
+        alg_bytes = 16.0 * P + 4.0 * BUNCH * (sum(LAYERS[:-1]) + sum(LAYERS[1:]))
+        traffic, tsrc = None, None
+        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+                for k, v in pm.get("kernels", pm).items():
+                    if "bp_gemm_multi" in k and "false, false, 3, 1, 8" in k:
+                        traffic = (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6
+                        tsrc = "profiles/" + name
+                if traffic is not None:
+                    break
+            except Exception:
+                continue
+        iso = {name: g.time_kernel(k, 100) for name, k in
+               (("fwd_hidden", 0), ("dgrad_hidden", 1), ("wgrad_update_hidden", 2), ("fwd_l1", 3), ("fwd_out", 4),
+                ("wgrad_update_l1", 5))}
+        res["roofline"] = {
+            "bound": "mfma", "kernel": "bp_gemm_multi<GemmKernel<64,64,32,2,2,false,false,EPI_WGRAD_UPDATE,1,8>> "
+                                       "(wgrad + fused momentum update of all 4 layers, one launch per step)",
+            "achieved": ach, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TF,
+            "traffic": traffic, "traffic_source": tsrc, "algorithmic_flops": wg_fl, "algorithmic_bytes": alg_bytes,
+            "kernel_ms": wg_ms, "measured_by": "HIP events inside 100 real steps on the launch stream (bp_profile_step)",
+            "kernels_in_step_ms": {k: v[0] for k, v in prof.items()}, "launches_per_step": {k: v[1] for k, v in prof.items()},
+            "hidden_fwd_2048x2048": {"achieved": 2.0 * BUNCH * 2048 * 2048 / (prof["fwd_hidden"][0] * 1e-3) / 1e12,
+                                     "frac": 2.0 * BUNCH * 2048 * 2048 / (prof["fwd_hidden"][0] * 1e-3) / 1e12 / PEAK_MFMA_F32_TF,
+                                     "unit": "TFLOP/s", "note": "north_star's 2048x2048 hidden GEMM, in-step"},
+            "kernels_isolated_ms": iso,
+            # skinny layers: achieved GB/s = 4*(prev*cur + B*prev + B*cur) / t, in-step
+            "skinny_layers_GBs": {
+                "fwd_l1_2827x2048": 4.0 * (LAYERS[0] * LAYERS[1] + BUNCH * (LAYERS[0] + LAYERS[1])) / (prof["fwd_l1"][0] * 1e-3) / 1e9,
+                "fwd_out_2048x257": 4.0 * (LAYERS[-2] * LAYERS[-1] + BUNCH * (LAYERS[-2] + LAYERS[-1])) / (prof["fwd_out"][0] * 1e-3) / 1e9},
+        }
+        if not args.no_extras:
+            mf, cp = g.measure_peaks()
+            res["roofline"]["peak_measured"] = {"mfma_f32_TFLOPs": mf, "hbm_copy_GBs": cp,
+                                                "frac_of_measured_mfma": ach / mf if mf > 0 else None,
+                                                "note": "bare v_mfma_f32_32x32x2_f32 loop and 1 GiB float4 copy, this device, this process"}
+    g.close()
+    if rank == 0 and not dp and not args.no_extras:
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-            for k, v in pm.get("kernels", pm).items():
-                if "bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>" in k:      # hidden-layer forward (TAG 0)
-                    traffic = (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6
-        except Exception:
-            traffic = None
-        res["roofline"] = {"bound": "mfma", "kernel": "bp_gemm<32,64,64,...,EPI_FWD_HIDDEN> (2048x2048 hidden fwd)",
-                           "achieved": ach, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TF,
-                           "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_hbm_traffic.json)",
-                           "algorithmic_bytes": 4.0 * (2048 * 2048 + 2 * BUNCH * 2048), "kernel_ms": ms,
-                           # skinny layers: achieved GB/s = 4*(prev*cur + B*prev + B*cur) / t
-                           "skinny_layers_GBs": {
-                               "fwd_l1_2827x2048": 4.0 * (LAYERS[0] * LAYERS[1] + BUNCH * (LAYERS[0] + LAYERS[1])) / (ms["fwd_l1"] * 1e-3) / 1e9,
-                               "fwd_out_2048x257": 4.0 * (LAYERS[-2] * LAYERS[-1] + BUNCH * (LAYERS[-2] + LAYERS[-1])) / (ms["fwd_out"] * 1e-3) / 1e9},
-                           "step_frac_of_mfma_peak": flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF}
-        if world == 1 and not force_dp and not args.no_cpu_baseline:
+            res["c5_bf16"] = c5_line(dnnse_amd, dev)
+        except Exception as e:
+            res["c5_bf16"] = {"error": str(e)[:300]}
+    if rank == 0:
+        if world == 1 and not dp and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, b)
-        try:                                   # anything native code left in C stdio (e.g. the RCCL banner) goes out first,
+        try:                                   # anything native code left in C stdio goes out first,
             import ctypes                      # so that the JSON line is the last thing on stdout
             ctypes.CDLL(None).fflush(None)
         except Exception:

@@ -34,8 +34,9 @@ ABI_SYMBOLS = [
     "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_dp_forward_layer", "bp_dp_dgrads", "bp_dp_wgrad_layer", "bp_apply_update_layer", "bp_advance_step",
     "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
     "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
-    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info",
+    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info", "bp_profile_step", "bp_measure_peaks",
 ]
+PROF_KINDS = ["fwd_l1", "fwd_hidden", "fwd_out", "dgrad_out", "dgrad_hidden", "wgrad_update_grouped"]
 
 
 class BPError(RuntimeError):
@@ -112,6 +113,8 @@ def load_library(path=None):
     lib.bp_set_stream.argtypes = [hp, C.c_void_p]
     lib.bp_last_train_ms.argtypes = [hp, fp, C.POINTER(C.c_int)]
     lib.bp_time_kernel.argtypes = [hp, C.c_int, C.c_int, fp]
+    lib.bp_profile_step.argtypes = [hp, C.c_int, C.c_int, fp, C.POINTER(C.c_int)]
+    lib.bp_measure_peaks.argtypes = [hp, fp, fp]
     lib.bp_set_hyper.argtypes = [hp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
     lib.bp_dp_attach.argtypes = [hp, C.c_int, C.c_int, C.c_char_p]
     lib.bp_dp_detach.argtypes = [hp]
@@ -367,6 +370,18 @@ class BP_GPU(object):
         ms = C.c_float()
         self._check(self._lib.bp_time_kernel(self._h, int(which), int(iters), C.byref(ms)))
         return float(ms.value)
+
+    def profile_step(self, first_frame, n_bunches):
+        """{class: (avg ms per launch inside the step, launches per step)} -- bp_profile_step."""
+        ms = (C.c_float * len(PROF_KINDS))()
+        cnt = (C.c_int * len(PROF_KINDS))()
+        self._check(self._lib.bp_profile_step(self._h, int(first_frame), int(n_bunches), ms, cnt))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(PROF_KINDS)}
+
+    def measure_peaks(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self._lib.bp_measure_peaks(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
 
     def close(self):
         if self._h is not None:

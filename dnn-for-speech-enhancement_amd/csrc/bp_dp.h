@@ -13,13 +13,19 @@
 // no host synchronisation and no collective library on the data path.  The reference moved the same
 // data through GPU 0 with cublasSaxpy / cublasScopy over P2P (BP_GPU.cu:863-904).
 //
-// Memory-model contract (gfx950; LLVM AMDGPU memory model, system scope):
-//   producer : payload stores -> every wave drains vmcnt -> one lane per workgroup system-scope
-//              release (buffer_wbl2 sc0 sc1) -> arrival counter -> the LAST workgroup stores the
-//              epoch into every peer's flag word (system-scope atomic store)
-//   consumer : a one-wave wait kernel polls its OWN flag words (system-scope relaxed loads, bounded
-//              spin) -> kernel boundary -> the reading kernel's workgroups each execute one
-//              system-scope acquire (buffer_inv sc0 sc1) before their first peer load.
+// Memory-model contract (gfx950; LLVM AMDGPU memory model).  No per-workgroup fences: a system-scope release or
+// acquire (buffer_wbl2 / buffer_inv sc0 sc1) acts on the whole L2 of the executing XCD, and one per workgroup made
+// the exchange kernel 5x slower and evicted the L2 under the GEMMs that run beside it (rocprofv3, round 2).  Instead
+//   * the gradient buffer is FINE-GRAINED device memory (never cached dirty; peers' mappings of it are uncached)
+//     and is read with system-scope (sc0 sc1) 16-byte loads, so a reader can neither see a stale L2 line nor leave one;
+//   * new weights are written with system-scope WRITE-THROUGH (sc0 sc1) 16-byte stores into the (cacheable) parameter
+//     arenas: nothing stays dirty in the writer's L2; the owner's L2 is kept coherent for its local memory by the
+//     fabric's probes, and its L1s are invalidated at the next kernel boundary;
+//   * ordering: every storing wave drains vmcnt (write-through stores are complete when acknowledged) ->
+//     __syncthreads -> agent-scope arrival counter -> the LAST workgroup stores the epoch into every peer's flag word
+//     (system-scope atomic store; flag words are fine-grained memory);
+//   * consumer: a one-wave wait kernel polls its OWN flag words (system-scope relaxed loads, bounded spin), and the
+//     kernel boundary behind it orders the reading kernel after the poll.
 // Spins are bounded by a wall-clock budget; a timeout raises the error word instead of hanging.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -33,12 +39,11 @@ __host__ __device__ inline int bp_dp_flag_index(int kind, int layer, int src) { 
 
 struct DpPeers { unsigned *flags[BP_DP_MAXRANKS]; };
 
-// One wave: after everything earlier on the stream is complete (kernel boundary) and a system-scope
-// release, lane p stores `epoch` into word `index` of peer p's flag array.
+// One wave: after everything earlier on the stream is complete (kernel boundary: the producing kernel's L2 write-back
+// has happened, and the gradient buffer is write-through fine-grained memory anyway), lane p stores `epoch` into word
+// `index` of peer p's flag array.
 __global__ void bp_dp_signal(DpPeers peers, int world, int index, unsigned epoch)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int p = threadIdx.x;
     if (p < world) __hip_atomic_store(peers.flags[p] + index, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -59,7 +64,6 @@ __global__ void bp_dp_wait(const unsigned *flags, int base, int world, unsigned 
             __builtin_amdgcn_s_sleep(16);
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
 struct DpReduceArgs {
@@ -74,47 +78,73 @@ struct DpReduceArgs {
     DpPeers peers; int flag_index; unsigned epoch;
 };
 
+#ifndef BP_DP_UNROLL
+#define BP_DP_UNROLL 4
+#endif
+// 16-byte system-scope accesses through a buffer descriptor (aux: sc0 = 1, sc1 = 16)
+typedef float bp_f32x4 __attribute__((ext_vector_type(4)));
+#define BP_AUX_SYS (1 | 16)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bp_rsrc(const void *p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+
 // Slice [lo, hi) of one layer: g = sum over ranks (fixed order 0..world-1, so the result does not depend on
-// which rank owns the slice), momentum update of delta/W, new W to every rank.  One thread = 4 floats.
+// which rank owns the slice), momentum update of delta/W, new W to every rank.  One thread = 4 floats per pass.
 template <int WORLD>
 __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
 {
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // peers' gradients: drop stale lines
-    __syncthreads();
     const int world = WORLD > 0 ? WORLD : a.world;
+    const unsigned bytes = (unsigned)((a.hi - a.lo) * 4);
+    __amdgpu_buffer_rsrc_t rg[BP_DP_MAXRANKS], rw[BP_DP_MAXRANKS];
+#pragma unroll
+    for (int p = 0; p < BP_DP_MAXRANKS; ++p)
+        if (p < world) { rg[p] = bp_rsrc(a.grads[p] + a.lo, bytes); rw[p] = bp_rsrc(a.params[p] + a.lo, bytes); }
+    const float *w_own = a.params[a.rank] + a.lo;
+    float *d_own = a.delta + a.lo;
     const unsigned long long n4 = (a.hi - a.lo) >> 2, stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-        const unsigned long long i = a.lo + 4 * q;
-        float4 g[BP_DP_MAXRANKS];
+    // U float4 per thread and pass: U * world peer loads in flight per lane (xGMI latency), few workgroups resident
+    // (the exchange runs beside the next minibatch's GEMMs and must not crowd them out of the CUs' memory pipes)
+    constexpr int U = BP_DP_UNROLL;
+    for (unsigned long long q0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < n4; q0 += U * stride) {
+        float4 w[U], d[U];
+        bp_f32x4 g[U][BP_DP_MAXRANKS];
 #pragma unroll
-        for (int p = 0; p < BP_DP_MAXRANKS; ++p)
-            if (p < world) g[p] = *reinterpret_cast<const float4 *>(a.grads[p] + i);
-        const float4 w = *reinterpret_cast<const float4 *>(a.params[a.rank] + i);
-        const float4 d = *reinterpret_cast<const float4 *>(a.delta + i);
-        float4 s = g[0];
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long q = q0 + u * stride < n4 ? q0 + u * stride : q0;     // (clamped: loads stay unconditional)
+            w[u] = *reinterpret_cast<const float4 *>(w_own + 4 * q);
+            d[u] = *reinterpret_cast<const float4 *>(d_own + 4 * q);
 #pragma unroll
-        for (int p = 1; p < BP_DP_MAXRANKS; ++p)
-            if (p < world) { s.x += g[p].x; s.y += g[p].y; s.z += g[p].z; s.w += g[p].w; }
-        const float wc = i < a.w_end ? a.wc : 0.0f;                     // (segments are multiples of 64 floats: a float4 never straddles)
-        float4 dn, wn;
-        dn.x = a.mom * d.x - a.c1 * (s.x / a.ndiv + wc * w.x); wn.x = dn.x + 1.0f * w.x;   // kernUpdatedelta, kernAccSum
-        dn.y = a.mom * d.y - a.c1 * (s.y / a.ndiv + wc * w.y); wn.y = dn.y + 1.0f * w.y;
-        dn.z = a.mom * d.z - a.c1 * (s.z / a.ndiv + wc * w.z); wn.z = dn.z + 1.0f * w.z;
-        dn.w = a.mom * d.w - a.c1 * (s.w / a.ndiv + wc * w.w); wn.w = dn.w + 1.0f * w.w;
-        *reinterpret_cast<float4 *>(a.delta + i) = dn;
+            for (int p = 0; p < BP_DP_MAXRANKS; ++p)
+                if (p < world) g[u][p] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg[p], (unsigned)(q * 16), 0, BP_AUX_SYS));
+        }
 #pragma unroll
-        for (int p = 0; p < BP_DP_MAXRANKS; ++p)
-            if (p < world) *reinterpret_cast<float4 *>(a.params[p] + i) = wn;
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long q = q0 + u * stride;
+            if (q >= n4) break;
+            bp_f32x4 s = g[u][0];
+#pragma unroll
+            for (int p = 1; p < BP_DP_MAXRANKS; ++p)
+                if (p < world) s += g[u][p];
+            const float wc = a.lo + 4 * q < a.w_end ? a.wc : 0.0f;      // (segments are multiples of 64 floats: a float4 never straddles)
+            float4 dn; bp_f32x4 wn;
+            dn.x = a.mom * d[u].x - a.c1 * (s.x / a.ndiv + wc * w[u].x); wn.x = dn.x + 1.0f * w[u].x;   // kernUpdatedelta, kernAccSum
+            dn.y = a.mom * d[u].y - a.c1 * (s.y / a.ndiv + wc * w[u].y); wn.y = dn.y + 1.0f * w[u].y;
+            dn.z = a.mom * d[u].z - a.c1 * (s.z / a.ndiv + wc * w[u].z); wn.z = dn.z + 1.0f * w[u].z;
+            dn.w = a.mom * d[u].w - a.c1 * (s.w / a.ndiv + wc * w[u].w); wn.w = dn.w + 1.0f * w[u].w;
+            *reinterpret_cast<float4 *>(d_own + 4 * q) = dn;
+#pragma unroll
+            for (int p = 0; p < BP_DP_MAXRANKS; ++p)
+                if (p < world)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, wn), rw[p], (unsigned)(q * 16), 0, BP_AUX_SYS);
+        }
     }
-    // publish: drain, release at system scope once per workgroup, then the last workgroup raises the flags
+    // publish: every wave drains its write-through stores, then the last workgroup to arrive raises the flags
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ unsigned last;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0)
         last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    }
     __syncthreads();
     if (last) {
         if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -126,7 +156,7 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
 // Momentum slices of the peers into the local arena (bp_get_deltas on a data-parallel handle): plain copy.
 __global__ void bp_dp_copy(float *dst, const float *src, unsigned long long n4)
 {
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (rare call: one system-scope acquire per workgroup is fine here)
     __syncthreads();
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride)

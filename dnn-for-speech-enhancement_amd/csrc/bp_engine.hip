@@ -53,6 +53,7 @@ struct bp_handle {
     float *params, *deltas;
     float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
     struct bp_dp *dp;            // attached data-parallel group (bp_dp_attach) or null
+    struct StepProf *prof;       // bp_profile_step in progress: an event after every launch of the step
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
     float *in, *in_drop, *targ, *out_dev;
     float *slabs; size_t slab_stride; int out_splits;   // split-K workspace of the output layer
@@ -83,6 +84,24 @@ struct bp_handle {
     bf16_t *dxb[BP_MAXLAYER], *dxbT[BP_MAXLAYER];
 };
 
+// bp_profile_step: one HIP event after every launch of the step on the launch stream; the duration attributed to a
+// launch is the time between the previous event and its own (= kernel + the dependent-launch boundary in front of it).
+struct StepProf {
+    std::vector<hipEvent_t> ev; std::vector<int> kind; size_t used;
+};
+static hipError_t prof_mark(bp_handle *h, int kind)
+{
+    StepProf *p = h->prof;
+    if (!p) return hipSuccess;
+    if (p->used == p->ev.size()) {
+        hipEvent_t e; hipError_t er = hipEventCreate(&e);
+        if (er != hipSuccess) return er;
+        p->ev.push_back(e); p->kind.push_back(kind);
+    }
+    p->kind[p->used] = kind;
+    return hipEventRecord(p->ev[p->used++], h->stream);
+}
+
 static uint32_t drop_threshold(float p)
 {
     double t = (double)p * 4294967296.0;
@@ -92,7 +111,7 @@ static uint32_t drop_threshold(float p)
 }
 
 extern "C" const char *bp_last_error(void) { return g_err.c_str(); }
-extern "C" int bp_abi_version(void) { return 2; }   // 2: bp_config.compute_dtype, bp_window_chunk
+extern "C" int bp_abi_version(void) { return 3; }   // 3: bp_dp_attach (in-library exchange), bp_set_hyper, bp_profile_step
 extern "C" const char *bp_build_target(void) { return "gfx950"; }
 
 // Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM
@@ -585,19 +604,21 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
     }
     const float *tg = h->targ + (size_t)first * h->ld[L - 1];
     if (h->bf) return bf_bunch(h, x0, tg, fused);
-    for (int l = 1; l < L; ++l)
+    for (int l = 1; l < L; ++l) {
         CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
+        CKE(prof_mark(h, l == 1 ? BP_PROF_FWD_L1 : (l == L - 1 ? BP_PROF_FWD_OUT : BP_PROF_FWD_HIDDEN)));
+    }
     // Every dgrad of the step reads pre-update weights (BP_GPU.cu:636 runs before :643-652 of the same
     // layer and the lower layers' updates come later), so the wgrad+update problems can all wait until
     // the last dgrad and share grouped launches (bp_gemm_multi), layer 1 (the largest) first.
     Prepared ws[BP_MAXLAYER]; int nw = 0;
     for (int l = L - 1; l >= 1; --l) {
-        if (l != 1) CKE(launch_dgrad(h, h->stream, l, B));
+        if (l != 1) { CKE(launch_dgrad(h, h->stream, l, B)); CKE(prof_mark(h, l == L - 1 ? BP_PROF_DGRAD_OUT : BP_PROF_DGRAD_HIDDEN)); }
         if (h->grouped) ws[nw++] = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
-        else CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], fused));
+        else { CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], fused)); CKE(prof_mark(h, BP_PROF_WGRAD)); }
     }
     for (int i = 0; i < nw / 2; ++i) { Prepared t = ws[i]; ws[i] = ws[nw - 1 - i]; ws[nw - 1 - i] = t; }
-    if (nw) CKE(run_wgrads(h->stream, ws, nw, true));
+    if (nw) { CKE(run_wgrads(h->stream, ws, nw, true)); CKE(prof_mark(h, BP_PROF_WGRAD)); }
 #undef CKE
     return hipSuccess;
 }
@@ -1001,6 +1022,7 @@ struct bp_dp {
     DpShm *shm; std::string shm_name;
     float *p_params[BP_DP_MAXRANKS], *p_grad[BP_DP_MAXRANKS], *p_deltas[BP_DP_MAXRANKS];
     unsigned *p_flags[BP_DP_MAXRANKS];
+    float *grad_fine, *grad_prev; // fine-grained gradient buffer used while attached / the handle's own one (restored at detach)
     unsigned *flags;              // own flag words (fine-grained device memory, exported)
     unsigned *arrive;             // [BP_MAXLAYER] last-arriver counters of bp_dp_reduce_update
     unsigned *err;                // pinned host word the wait kernels raise on timeout
@@ -1051,6 +1073,7 @@ static void dp_release(bp_handle *h)
     for (auto &e : d->ev_g) if (e) (void)hipEventDestroy(e);
     if (d->ev_comm) (void)hipEventDestroy(d->ev_comm);
     if (d->comm) (void)hipStreamDestroy(d->comm);
+    if (d->grad_fine) { if (h->grad == d->grad_fine) h->grad = d->grad_prev; (void)hipFree(d->grad_fine); }
     if (d->flags) (void)hipFree(d->flags);
     if (d->arrive) (void)hipFree(d->arrive);
     if (d->err) (void)hipHostFree(d->err);
@@ -1090,14 +1113,21 @@ extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
     d->budget_ticks = (unsigned long long)(dp_timeout_s() * 1.0e8);      // wall_clock64: 100 MHz
 #define DK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string("bp_dp_attach: ") + #x + ": " + hipGetErrorString(_e); \
         if (d->shm) d->shm->abort_flag.store(1); dp_release(h); return fail(BP_ERR_DEVICE, m); } } while (0)
-    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) { dp_release(h); return r; } }
+    // the gradient buffer peers read: fine-grained (uncached in every mapping, written through by the wgrad kernels)
+    DK(hipExtMallocWithFlags((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float), hipDeviceMallocFinegrained));
+    DK(hipMemset(d->grad_fine, 0, (h->grad_floats + SLACK) * sizeof(float)));
+    d->grad_prev = h->grad; h->grad = d->grad_fine;
     DK(hipExtMallocWithFlags((void **)&d->flags, BP_DP_FLAG_WORDS * sizeof(unsigned), hipDeviceMallocFinegrained));
     DK(hipMemset(d->flags, 0, BP_DP_FLAG_WORDS * sizeof(unsigned)));
     DK(hipMalloc((void **)&d->arrive, BP_MAXLAYER * sizeof(unsigned)));
     DK(hipMemset(d->arrive, 0, BP_MAXLAYER * sizeof(unsigned)));
     DK(hipHostMalloc((void **)&d->err, sizeof(unsigned), hipHostMallocMapped));
     *d->err = 0u;
-    DK(hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking));
+    {   // the exchange yields to the GEMMs of the main stream when both have workgroups to place
+        int lo_prio = 0, hi_prio = 0;
+        DK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
+        DK(hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, getenv("BP_DP_COMM_PRIO_NORMAL") ? 0 : lo_prio));
+    }
     for (int l = 1; l < h->L; ++l) DK(hipEventCreateWithFlags(&d->ev_g[l], hipEventDisableTiming));
     DK(hipEventCreateWithFlags(&d->ev_comm, hipEventDisableTiming));
     DK(hipStreamSynchronize(h->stream));
@@ -1192,8 +1222,11 @@ static hipError_t dp_exchange_layer(bp_handle *h, int l)
     a.mom = m; a.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; a.wc = h->cfg.weightcost; a.ndiv = (float)h->Bg;
     a.arrive = d->arrive + l; a.peers = peers; a.flag_index = bp_dp_flag_index(BP_DP_FLAG_W, l, d->rank); a.epoch = d->epoch;
     const size_t n4 = (a.hi - a.lo) / 4;
-    int grid = (int)((n4 + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    static const int max_grid = getenv("BP_DP_GRID") ? atoi(getenv("BP_DP_GRID")) : 128;   // development A/B switch
+    // few, deep workgroups: at 2048 workgroups the exchange kernel crowds the GEMMs it runs beside out of the CUs'
+    // memory pipes (C2 step through the exchange path on one GPU: 0.51 ms at 2048, 0.34 at 512, 0.28 at 128, 0.31 at 64)
+    int grid = (int)((n4 + 256 * BP_DP_UNROLL - 1) / (256 * BP_DP_UNROLL));
+    if (grid > max_grid) grid = max_grid;
     if (grid < 1) grid = 1;                                    // (an empty slice still raises its flag)
     switch (d->world) {
     case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
@@ -1391,6 +1424,110 @@ static int get_params(bp_handle *h, float *const *w, float *const *b, bool delta
 }
 extern "C" int bp_get_weights(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, false); }
 extern "C" int bp_get_deltas(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, true); }
+
+
+// ------------------------------------------------------------------ in-step kernel timing + measured peaks
+// bp_train_resident over [first_frame, first_frame + n_bunches*bunchsize) with an event after every launch: the
+// per-class average duration of the step's kernels AS THEY RUN IN THE STEP (same order, same cache state as the
+// timed loop), for the roofline object.  Classes: BP_PROF_* in bp_c_api.h.  fp32 single-device handles only.
+extern "C" int bp_profile_step(bp_handle *h, int first_frame, int n_bunches, float *avg_ms, int *launches_per_step)
+{
+    if (!h || !avg_ms) return fail(BP_ERR_ARG, "bp_profile_step: null argument");
+    if (h->bf || h->dp || h->Bg != h->B) return fail(BP_ERR_STATE, "bp_profile_step: fp32 single-device handles only");
+    if (n_bunches < 1 || first_frame < 0 || (long)first_frame + (long)n_bunches * h->B > h->chunk_frames)
+        return fail(BP_ERR_ARG, "bp_profile_step: frame range outside the resident chunk");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    StepProf prof; prof.used = 0;
+    int rc = BP_OK;
+    if (use_mask(h)) HIPCHK(mask_range(h, first_frame, n_bunches * h->B));
+    h->prof = &prof;
+    hipError_t er = prof_mark(h, -1);                        // origin
+    for (int i = 0; er == hipSuccess && i < n_bunches; ++i) {
+        er = bunch(h, first_frame + i * h->B, true);
+        h->step++;
+    }
+    h->prof = nullptr;
+    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
+    double sum[BP_PROF_KINDS] = {0}; long cnt[BP_PROF_KINDS] = {0};
+    for (size_t k = 1; er == hipSuccess && k < prof.used; ++k) {
+        float ms = 0.f;
+        er = hipEventElapsedTime(&ms, prof.ev[k - 1], prof.ev[k]);
+        if (prof.kind[k] >= 0 && prof.kind[k] < BP_PROF_KINDS) { sum[prof.kind[k]] += ms; cnt[prof.kind[k]]++; }
+    }
+    for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
+    if (er != hipSuccess) rc = fail(BP_ERR_DEVICE, std::string("bp_profile_step: ") + hipGetErrorString(er));
+    for (int k = 0; k < BP_PROF_KINDS; ++k) {
+        avg_ms[k] = cnt[k] ? (float)(sum[k] / (double)cnt[k]) : 0.f;
+        if (launches_per_step) launches_per_step[k] = (int)(cnt[k] / n_bunches);
+    }
+    return rc;
+}
+
+// Measured peaks of THIS device, taken in the same process as the benchmark: a bare v_mfma_f32_32x32x2_f32 loop
+// (4 independent accumulator chains per wave, 4 waves per SIMD-quad workgroup, no memory traffic) and a float4
+// device-to-device copy of 2 x 1 GiB (read + write bytes counted).
+__global__ __launch_bounds__(256) void bp_peak_mfma_f32(float *sink, int iters, float seed)
+{
+    f32x16 a0, a1, a2, a3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = seed; a1[r] = seed; a2[r] = seed; a3[r] = seed; }
+    const float x = seed + (float)threadIdx.x * 1e-9f, y = seed * 0.5f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    if (s == 1.2345e-30f) sink[threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void bp_peak_copy(float4 *dst, const float4 *src, size_t n4)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+extern "C" int bp_measure_peaks(bp_handle *h, float *mfma_f32_tflops, float *hbm_copy_gbs)
+{
+    if (!h || !mfma_f32_tflops || !hbm_copy_gbs) return fail(BP_ERR_ARG, "bp_measure_peaks: null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    float *sink = nullptr;
+    HIPCHK(hipMalloc((void **)&sink, 4096));
+    const int iters = 4096, wgs = 256 * 8;
+    float ms = 0.f, best = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {
+        HIPCHK(hipEventRecord(a, h->stream));
+        hipLaunchKernelGGL(bp_peak_mfma_f32, dim3(wgs), dim3(256), 0, h->stream, sink, iters, 1.0f);
+        HIPCHK(hipEventRecord(b, h->stream));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        const float tf = (float)((double)wgs * 4 * iters * 4 * (2.0 * 32 * 32 * 2) / (ms * 1e-3) / 1e12);
+        if (rep > 0 && tf > best) best = tf;
+    }
+    *mfma_f32_tflops = best;
+    (void)hipFree(sink);
+    const size_t bytes = (size_t)1 << 30;
+    float4 *src = nullptr, *dst = nullptr;
+    HIPCHK(hipMalloc((void **)&src, bytes)); HIPCHK(hipMalloc((void **)&dst, bytes));
+    HIPCHK(hipMemsetAsync(src, 1, bytes, h->stream));
+    best = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {
+        HIPCHK(hipEventRecord(a, h->stream));
+        hipLaunchKernelGGL(bp_peak_copy, dim3(256 * 16), dim3(256), 0, h->stream, dst, src, bytes / 16);
+        HIPCHK(hipEventRecord(b, h->stream));
+        HIPCHK(hipEventSynchronize(b));
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        const float gbs = (float)(2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+        if (rep > 0 && gbs > best) best = gbs;
+    }
+    *hbm_copy_gbs = best;
+    (void)hipFree(src); (void)hipFree(dst);
+    HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b));
+    return BP_OK;
+}
 
 // ------------------------------------------------------------------ isolated kernel timing
 extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)

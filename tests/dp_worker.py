@@ -58,8 +58,9 @@ def main():
     g.train(idx.size - half, x[idx[half:]], t[idx[half:]])
     w, bb = g.get_weights()
     dw, dbb = g.get_deltas()                      # collective: gathers the sharded momentum state
-    cv = g.CrossValid(min(x.shape[0], 3 * B + 1), x, t)
-    out = {"cv": np.float64(cv), "epochs": np.int64(g.dp_info()[2])}
+    n_cv = min(x.shape[0], 3 * B + 1)
+    cv = g.CrossValid(n_cv, x, t)
+    out = {"cv": np.float64(cv), "epochs": np.int64(g.dp_info()[2]), "out": g.forward(x[:n_cv])}
     for l in range(1, len(ls)):
         out["W%d" % l], out["b%d" % l], out["dW%d" % l], out["db%d" % l] = w[l], bb[l], dw[l], dbb[l]
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)
