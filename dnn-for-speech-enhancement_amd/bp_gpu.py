@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_dp_forward_layer", "bp_dp_dgrads", "bp_dp_wgrad_layer", "bp_apply_update_layer", "bp_advance_step",
     "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
     "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
-    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info", "bp_profile_step", "bp_measure_peaks",
+    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info", "bp_profile_step", "bp_measure_peaks", "bp_device_count",
 ]
 PROF_KINDS = ["fwd_l1", "fwd_hidden", "fwd_out", "dgrad_out", "dgrad_hidden", "wgrad_update_grouped"]
 

@@ -113,6 +113,12 @@ static uint32_t drop_threshold(float p)
 extern "C" const char *bp_last_error(void) { return g_err.c_str(); }
 extern "C" int bp_abi_version(void) { return 3; }   // 3: bp_dp_attach (in-library exchange), bp_set_hyper, bp_profile_step
 extern "C" const char *bp_build_target(void) { return "gfx950"; }
+extern "C" int bp_device_count(int *n)
+{
+    if (!n) return fail(BP_ERR_ARG, "null argument");
+    HIPCHK(hipGetDeviceCount(n));
+    return BP_OK;
+}
 
 // Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM
 // loaders (no predicates, see GemmArgs) stay inside the allocation.

@@ -5,6 +5,12 @@
 // MI355X library through the drop-in class include/BP_GPU.h; the Perl epoch driver
 // (finetune_DNN_speech_enhancement_dropout_NAT.pl) can call this binary unchanged.
 //
+// gpu_used=N (N > 1) is data parallel, which the reference only has as commented-out code (BP_GPU.cu:29-36, 775-908):
+// the process forks N ranks, one per GPU (rank r on device r % visible devices); `bunchsize` is the GLOBAL minibatch as
+// in the reference's per-GPU split (BP_GPU.cu:29-36), every rank trains on its bunchsize/N frames of each minibatch and
+// the library exchanges gradients / weights itself (bp_dp_attach, include/bp_c_api.h).  Rank 0 writes the log, the
+// weights file and runs the cross-validation.
+//
 // Extra optional keys (defaults = live reference behaviour): activation=relu|sigmoid,
 // momentum_rule=live|classic, seed=<u64> (dropout stream), device=<ordinal>, compute=fp32|bf16;
 // stack=device|host (default device: raw frames + index tables go to the GPU, which builds the context
@@ -13,7 +19,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/wait.h>
 #include <time.h>
+#include <unistd.h>
 
 #include <functional>
 #include <future>
@@ -31,7 +39,20 @@ struct Params {
     float momentum = 0, weightcost = 0, lrate = 0, visible_omit = 0, hid_omit = 0;
     float wmin = -0.1f, wmax = 0.1f, bmin = -0.1f, bmax = 0.1f;          // Interface.cc:79-82
     bool stack_on_device = true, prefetch = true;
+    int activation = 0, momentum_rule = 0, device = -1, compute_dtype = 0;
+    unsigned long long dropout_seed = 0;
 };
+
+// Rows of a chunk that rank `rank` of `world` trains on: its B = Bg/world frames of every full global minibatch
+// (rows i*Bg + rank*B ... of minibatch i; the partial last minibatch is dropped as in BP_GPU.cu:315-318).
+static std::vector<int> shard_rows(int n_samples, int global_bunch, int world, int rank)
+{
+    const int B = global_bunch / world, nb = n_samples / global_bunch;
+    std::vector<int> idx((size_t)nb * B);
+    for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < B; ++j) idx[(size_t)i * B + j] = i * global_bunch + rank * B + j;
+    return idx;
+}
 
 typedef bp::PfileReader::WindowChunk WindowChunk;
 static bp_window_chunk describe(const WindowChunk &w, int context)
@@ -79,11 +100,6 @@ static void parse_range(const std::string &r, int *st, int *en, FILE *log)
     *en = atoi(r.substr(p + 1).c_str());
 }
 
-static void rand_weight(float *v, float mn, float mx, size_t n)        // Interface::GetRandWeight, Interface.cc:1036-1042
-{
-    for (size_t i = 0; i < n; ++i) v[i] = drand48() * (mx - mn) + mn;
-}
-
 int main(int argc, char **argv)
 {
     const double t_start = (double)time(NULL);
@@ -115,20 +131,39 @@ int main(int argc, char **argv)
                 pos = c + 1;
             }
         }
-        // switches the reference only has as source edits (forwarded to the shim through its environment keys)
-        else if (k == "activation") setenv("BP_ACTIVATION", v.c_str(), 1);
-        else if (k == "momentum_rule") setenv("BP_MOMENTUM_RULE", v.c_str(), 1);
-        else if (k == "seed") setenv("BP_SEED", v.c_str(), 1);
-        else if (k == "device") setenv("BP_DEVICE", v.c_str(), 1);
-        else if (k == "compute") setenv("BP_COMPUTE_DTYPE", v.c_str(), 1);      // fp32 (default) | bf16
+        // switches the reference only has as source edits (handed to the shim in its bp_config constructor)
+        else if (k == "activation") P.activation = v == "sigmoid" ? 1 : 0;
+        else if (k == "momentum_rule") P.momentum_rule = v == "classic" ? 1 : 0;
+        else if (k == "seed") P.dropout_seed = strtoull(v.c_str(), 0, 10);
+        else if (k == "device") P.device = atoi(v.c_str());
+        else if (k == "compute") P.compute_dtype = v == "bf16" ? 1 : 0;         // fp32 (default) | bf16
         else if (k == "stack") P.stack_on_device = (v != "host");
         else if (k == "prefetch") P.prefetch = atoi(v.c_str()) != 0;
         // unknown names are silently ignored, as in the reference (e.g. the .pl passes numlayers=)
     }
-    FILE *log = fopen(P.log_file.c_str(), "wt");
+    // ---- gpu_used > 1: fork the data-parallel ranks before anything touches files or the GPU
+    const int world = P.gpu_used > 1 ? P.gpu_used : 1;
+    int rank = 0;
+    std::vector<pid_t> kids;
+    const std::string dp_key = "bptrain-" + std::to_string((long)getpid());
+    if (world > 1) {
+        if (world > 8 || P.bunchsize % world != 0) {
+            printf("gpu_used=%d: needs 2..8 GPUs and a bunchsize that is a multiple of it\n", world);
+            exit(0);
+        }
+        fflush(stdout);
+        for (int r = 1; r < world; ++r) {
+            const pid_t c = fork();
+            if (c < 0) { printf("fork failed\n"); exit(0); }
+            if (c == 0) { rank = r; kids.clear(); break; }
+            kids.push_back(c);
+        }
+    }
+    const bool lead = rank == 0;
+    FILE *log = fopen(lead ? P.log_file.c_str() : "/dev/null", "wt");
     if (!log) { printf("can not open output log file: %s\n", P.log_file.c_str()); exit(0); }
-    FILE *fp_out = fopen(P.outwts_file.c_str(), "wb");
-    if (!fp_out) { fprintf(log, "can not open output weights file: %s\n", P.outwts_file.c_str()); exit(0); }
+    FILE *fp_out = lead ? fopen(P.outwts_file.c_str(), "wb") : nullptr;
+    if (lead && !fp_out) { fprintf(log, "can not open output weights file: %s\n", P.outwts_file.c_str()); exit(0); }
     const int L = P.numlayers;
     if (L < 2 || L > MAXLAYER - 1) { fprintf(log, "layersizes: need 2..%d layer sizes\n", MAXLAYER - 1); exit(0); }
     // parameter echo (Interface.cc:267-298)
@@ -181,10 +216,7 @@ int main(int argc, char **argv)
     srand48(P.seed);                                    // once, for weights and every shuffle (Interface.cc:338)
     if (P.initwts_file.empty()) {
         fprintf(log, "Getting Randemed initial weights...\n");
-        for (int i = 1; i < L; ++i) {
-            rand_weight(weights[i], P.wmin, P.wmax, Wv[i].size());
-            rand_weight(bias[i], P.bmin, P.bmax, Bv[i].size());
-        }
+        bp::random_weights(L, P.layersizes, weights, bias, P.wmin, P.wmax, P.bmin, P.bmax);
         fprintf(log, "Randemed initial weights getted.\n");
     } else {
         FILE *fi = fopen(P.initwts_file.c_str(), "rb");
@@ -202,8 +234,24 @@ int main(int argc, char **argv)
     }
 
     // ---- BPtrain.cc:31-96
-    BP_GPU *TrainObj = new BP_GPU(P.gpu_used, L, P.layersizes, P.bunchsize, P.lrate, P.momentum, P.weightcost, weights, bias,
-                                  P.dropoutflag, P.visible_omit, P.hid_omit);
+    bp_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.gpu_used = P.gpu_used > 0 ? P.gpu_used : 1; cfg.numlayers = L;
+    for (int i = 0; i < L; ++i) cfg.layersizes[i] = P.layersizes[i];
+    cfg.bunchsize = P.bunchsize / world;                    // BP_GPU.cu:29-36: the bunch is split over the GPUs
+    cfg.lrate = P.lrate; cfg.momentum = P.momentum; cfg.weightcost = P.weightcost;
+    cfg.dropoutflag = P.dropoutflag; cfg.visible_omit = P.visible_omit; cfg.hid_omit = P.hid_omit;
+    cfg.activation = P.activation; cfg.momentum_rule = P.momentum_rule; cfg.seed = P.dropout_seed; cfg.compute_dtype = P.compute_dtype;
+    cfg.max_chunk_frames = P.traincache;
+    if (P.gpu_used < 1) { printf("GPU Num %d Not In Range %d-\n", P.gpu_used, 1); exit(0); }      // BP_GPU.cu:20-24
+    if (P.device >= 0) cfg.device = P.device + (world > 1 ? rank : 0);
+    else if (world > 1) {
+        int ndev = 1;
+        if (bp_device_count(&ndev) != 0 || ndev < 1) { printf("%s\n", bp_last_error()); exit(0); }
+        cfg.device = rank % ndev;
+    }
+    if (lead) printf("Use GPU Device : %d\n", P.gpu_used);
+    BP_GPU *TrainObj = new BP_GPU(cfg, weights, bias, world, rank, dp_key.c_str());
     fprintf(log, "Get pfile info over: Training data has %u frames, %u sentences.\n", reader.total_frames(), reader.total_sents());
     int st, en;
     parse_range(P.train_range, &st, &en, log);
@@ -221,7 +269,31 @@ int main(int argc, char **argv)
             const WindowChunk &w = chunks.get(i);           // (the read of chunk i+1 is now running behind us)
             fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, w.n_samples);
             fflush(log);
-            if (P.stack_on_device) {
+            if (world > 1) {
+                // this rank's rows of every global minibatch
+                const std::vector<int> rows = shard_rows(w.n_samples, P.bunchsize, world, rank);
+                if (lead && w.n_samples % P.bunchsize)
+                    printf("this bunch has only %d samples and is ignored.\n", w.n_samples % P.bunchsize);   // BP_GPU.cu:317
+                if (P.stack_on_device) {
+                    std::vector<int> ws(rows.size()), tf(rows.size()), nr(w.nat_row.empty() ? 0 : rows.size());
+                    for (size_t k = 0; k < rows.size(); ++k) {
+                        ws[k] = w.win_start[rows[k]]; tf[k] = w.targ_frame[rows[k]];
+                        if (!nr.empty()) nr[k] = w.nat_row[rows[k]];
+                    }
+                    bp_window_chunk c = describe(w, P.fea_context);
+                    c.n_samples = (int)rows.size(); c.win_start = ws.data(); c.targ_frame = tf.data(); c.nat_row = nr.empty() ? nullptr : nr.data();
+                    TrainObj->train_windows(c);             // (returns once the tables are on the device)
+                } else {
+                    reader.expand(w, indata.data(), targ.data());
+                    const int s0 = P.layersizes[0], sL = P.layersizes[L - 1];
+                    std::vector<float> xin(rows.size() * (size_t)s0), xtg(rows.size() * (size_t)sL);
+                    for (size_t k = 0; k < rows.size(); ++k) {
+                        memcpy(&xin[k * s0], &indata[(size_t)rows[k] * s0], sizeof(float) * s0);
+                        memcpy(&xtg[k * sL], &targ[(size_t)rows[k] * sL], sizeof(float) * sL);
+                    }
+                    TrainObj->train((int)rows.size(), xin.data(), xtg.data());
+                }
+            } else if (P.stack_on_device) {
                 TrainObj->train_windows(describe(w, P.fea_context));
             } else {
                 reader.expand(w, indata.data(), targ.data());
@@ -229,9 +301,13 @@ int main(int argc, char **argv)
             }                                               // both return once the chunk is on the device; the
         }                                                   // GPU works on it while the next one is prepared
     }
-    printf("begin to write weights\n");
+    if (lead) printf("begin to write weights\n");
     TrainObj->returnWeights(weights, bias);                 // (waits for the last chunk's bunches)
     clock_gettime(CLOCK_MONOTONIC, &ts1);
+    if (world > 1) {
+        TrainObj->dp_detach();                              // collective; the weights are replicated on every rank
+        if (!lead) { delete TrainObj; fflush(stdout); _exit(1); }
+    }
     {
         const double dt = (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec);
         fprintf(log, "Training pass: %u samples in %.3f s (%.0f frames/s, reader + upload + GPU).\n", tp.total_samples, dt,
@@ -268,6 +344,7 @@ int main(int argc, char **argv)
     fprintf(log, "CV over. squared error: %f\n", cvacc);
     fflush(log);
     fprintf(log, "Total cost time: %.1f s.\n", (double)time(NULL) - t_start);
+    for (pid_t c : kids) { int st = 0; waitpid(c, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st) != 1) fprintf(log, "rank process %d ended abnormally\n", (int)c); }
     printf("all finish!\n");
     delete TrainObj;
     fclose(log);

@@ -42,4 +42,16 @@ std::string read_weights(FILE *fp, int L, const int *ls, float *const *weights, 
     return "";
 }
 
+static void rand_weight(float *v, float mn, float mx, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) v[i] = drand48() * (mx - mn) + mn;
+}
+void random_weights(int numlayers, const int *layersizes, float *const *weights, float *const *bias, float wmin, float wmax,
+                    float bmin, float bmax)
+{
+    for (int i = 1; i < numlayers; ++i) {
+        rand_weight(weights[i], wmin, wmax, (size_t)layersizes[i] * layersizes[i - 1]);
+        rand_weight(bias[i], bmin, bmax, (size_t)layersizes[i]);
+    }
+}
 }  // namespace bp

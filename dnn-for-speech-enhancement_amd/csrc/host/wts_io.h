@@ -9,4 +9,8 @@ namespace bp {
 void write_weights(FILE *fp, int numlayers, const int *layersizes, float *const *weights, float *const *bias);
 // returns an empty string on success, else the reference's log message
 std::string read_weights(FILE *fp, int numlayers, const int *layersizes, float *const *weights, float *const *bias);
+// random initial net when no initwts_file is given (Interface.cc:340-349 + GetRandWeight :1036-1042): per layer the
+// weights then the biases, each value drand48() * (max - min) + min, consuming the process-wide srand48 stream
+void random_weights(int numlayers, const int *layersizes, float *const *weights, float *const *bias, float wmin, float wmax,
+                    float bmin, float bmax);
 }  // namespace bp

@@ -12,7 +12,9 @@
  * Differences a caller can observe (all documented in DESIGN.md):
  *   - `a_GPU_selected` > 1 does not fan out inside one process (the reference's multi-GPU path
  *     is commented out and trains nothing, BP_GPU.cu:301-313); data parallelism is one process
- *     per GPU through bp_config.global_bunchsize / rank_frame_offset.
+ *     per GPU: the bp_config constructor below joins a group (bptrain gpu_used=N forks the ranks).
+ *   - the public members lrate / momentum / weightcost / dropoutflag / visible_omit / hid_omit are pushed into the
+ *     library at the start of every train / CrossValid call (the reference reads them per bunch, BP_GPU.cu:488-500).
  *   - train_bunch_single / train_bunch_multi / cv_bunch_single take DEVICE pointers in the
  *     reference and are only called from inside the class; they are not re-exported.
  *   - train_windows / CrossValid_windows are additions (on-device frame stacking).
@@ -38,9 +40,7 @@ public:
     /* BP_GPU.h:43-44 / BP_GPU.cu:10-12 */
     BP_GPU(int a_GPU_selected, int a_numlayers, int *a_layersizes, int a_bunchsize, float a_lrate, float a_momentum,
            float a_weightcost, float **weights, float **bias, int a_dropoutflag, float a_visible_omit, float a_hid_omit)
-        : numlayers(a_numlayers), bunchsize(a_bunchsize), lrate(a_lrate), momentum(a_momentum),
-          weightcost(a_weightcost), dropoutflag(a_dropoutflag), visible_omit(a_visible_omit), hid_omit(a_hid_omit),
-          handle_(0)
+        : handle_(0)
     {
         if (a_GPU_selected < 1) {                       /* BP_GPU.cu:20-24 */
             printf("GPU Num %d Not In Range %d-\n", a_GPU_selected, 1);
@@ -51,40 +51,56 @@ public:
         memset(&cfg, 0, sizeof(cfg));
         cfg.gpu_used = a_GPU_selected;
         cfg.numlayers = a_numlayers;
-        for (int i = 0; i < MAXLAYER; ++i) layersizes[i] = 0;
-        for (int i = 0; i < a_numlayers && i < MAXLAYER; ++i) cfg.layersizes[i] = layersizes[i] = a_layersizes[i];
+        for (int i = 0; i < a_numlayers && i < MAXLAYER; ++i) cfg.layersizes[i] = a_layersizes[i];
         cfg.bunchsize = a_bunchsize;
         cfg.lrate = a_lrate; cfg.momentum = a_momentum; cfg.weightcost = a_weightcost;
         cfg.dropoutflag = a_dropoutflag; cfg.visible_omit = a_visible_omit; cfg.hid_omit = a_hid_omit;
+        /* switches the reference has only as source edits: an UNMODIFIED caller (the reference's BPtrain.cc) can
+         * still reach them through the environment; callers that can be edited use the bp_config constructor below */
         const char *e;
         if ((e = getenv("BP_ACTIVATION")) != 0) cfg.activation = strcmp(e, "sigmoid") == 0 ? 1 : 0;
         if ((e = getenv("BP_MOMENTUM_RULE")) != 0) cfg.momentum_rule = strcmp(e, "classic") == 0 ? 1 : 0;
         if ((e = getenv("BP_SEED")) != 0) cfg.seed = strtoull(e, 0, 10);
         if ((e = getenv("BP_DEVICE")) != 0) cfg.device = atoi(e);
         if ((e = getenv("BP_COMPUTE_DTYPE")) != 0) cfg.compute_dtype = strcmp(e, "bf16") == 0 ? 1 : 0;
-        check(bp_create(&cfg, weights, bias, &handle_));
-        printf("Created net with %d layers, bunchsize %d.\n", numlayers, bunchsize);   /* BP_GPU.cu:196 */
+        init(cfg, weights, bias, 1, 0, 0);
+    }
+    /* Extension: explicit configuration (every bp_config field: activation, momentum rule, dropout seed, device,
+     * compute dtype, data-parallel geometry) instead of process environment, so that several trainers can coexist in one
+     * process.  dp_world > 1: this object is rank dp_rank of a data-parallel group of dp_world processes (one per
+     * GPU) named dp_key; cfg.bunchsize is then the frames of a minibatch THIS rank owns and the constructor fills in
+     * global_bunchsize / rank_frame_offset and joins the group (bp_dp_attach, bp_c_api.h). */
+    BP_GPU(const bp_config &a_cfg, float **weights, float **bias, int dp_world = 1, int dp_rank = 0, const char *dp_key = 0)
+        : handle_(0)
+    {
+        bp_config cfg = a_cfg;
+        if (dp_world > 1) { cfg.global_bunchsize = cfg.bunchsize * dp_world; cfg.rank_frame_offset = cfg.bunchsize * dp_rank; }
+        init(cfg, weights, bias, dp_world, dp_rank, dp_key);
     }
     ~BP_GPU() { bp_destroy(handle_); }
 
     /* BP_GPU.h:50 / BP_GPU.cu:241-331 */
-    void train(int n_frames, float *in, const float *targ) { check(bp_train_chunk(handle_, n_frames, in, targ)); }
+    void train(int n_frames, float *in, const float *targ) { push_hyper(); check(bp_train_chunk(handle_, n_frames, in, targ)); }
     /* BP_GPU.h:57 / BP_GPU.cu:408-479: returns the SUM of squared errors */
     float CrossValid(int n_frames, const float *in, const float *targ)
     {
         float e = 0.0f;
+        push_hyper();
         check(bp_cv_chunk(handle_, n_frames, in, targ, &e));
         return e;
     }
     /* Extensions (no reference counterpart): the same two calls with the frame stacking done on the
      * device from raw frames + index tables (bp_window_chunk, bp_c_api.h). */
-    void train_windows(const bp_window_chunk &c) { check(bp_train_chunk_windows(handle_, &c)); }
+    void train_windows(const bp_window_chunk &c) { push_hyper(); check(bp_train_chunk_windows(handle_, &c)); }
     float CrossValid_windows(const bp_window_chunk &c)
     {
         float e = 0.0f;
+        push_hyper();
         check(bp_cv_chunk_windows(handle_, &c, &e));
         return e;
     }
+    /* leave the data-parallel group (collective over its ranks); the weights stay valid on every rank */
+    void dp_detach() { check(bp_dp_detach(handle_)); }
     /* BP_GPU.h:60 / BP_GPU.cu:910-923 */
     void returnWeights(float **weights, float **bias) { check(bp_get_weights(handle_, weights, bias)); }
 
@@ -101,6 +117,17 @@ public:
 private:
     BP_GPU(const BP_GPU &);
     BP_GPU &operator=(const BP_GPU &);
+    void init(const bp_config &cfg, float **weights, float **bias, int dp_world, int dp_rank, const char *dp_key)
+    {
+        numlayers = cfg.numlayers; bunchsize = cfg.bunchsize; lrate = cfg.lrate; momentum = cfg.momentum;
+        weightcost = cfg.weightcost; dropoutflag = cfg.dropoutflag; visible_omit = cfg.visible_omit; hid_omit = cfg.hid_omit;
+        for (int i = 0; i < MAXLAYER; ++i) layersizes[i] = i < cfg.numlayers ? cfg.layersizes[i] : 0;
+        check(bp_create(&cfg, weights, bias, &handle_));
+        if (dp_world > 1) check(bp_dp_attach(handle_, dp_world, dp_rank, dp_key ? dp_key : "bp"));
+        printf("Created net with %d layers, bunchsize %d.\n", numlayers, bunchsize);   /* BP_GPU.cu:196 */
+    }
+    /* the reference reads these members afresh on every bunch (BP_GPU.cu:488-500): a caller may assign them between chunks */
+    void push_hyper() { check(bp_set_hyper(handle_, lrate, momentum, weightcost, dropoutflag, visible_omit, hid_omit)); }
     void check(int rc)
     {
         if (rc != 0) {             /* reference convention: message + exit(0) */

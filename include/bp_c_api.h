@@ -77,6 +77,8 @@ const char *bp_last_error(void);
 /* Library/ABI version and the gfx target the kernels were compiled for ("gfx950"). */
 int         bp_abi_version(void);
 const char *bp_build_target(void);
+/* Number of MI355X devices visible to the process (hipGetDeviceCount), for hosts that do not link the HIP runtime. */
+int         bp_device_count(int *n);
 
 /* BP_GPU::BP_GPU (BP_GPU.cu:10-197): select device, allocate device state, upload weights
  * and biases (index 1..numlayers-1).  Momentum state starts at zero (devnew_vf zero-fill,

@@ -4,9 +4,13 @@
 //               <sent_st> <sent_en> <shuffle 0|1> <seed> <out.bin>
 //     out.bin: int32 nchunks, total_samples, chunk_frame_st[nchunks]; per chunk: int32 n, float in[n*input_dim], targ[n*out_dim]
 //   reader_dump wts <in.wts> <out.wts> <numlayers> <s0> <s1> ...        (read + re-write a weights file)
+//   reader_dump epoch <out.bin> name=value ...    one epoch's data path with THIS repo's host code, in the layout that
+//               oracle/ref_driver.cc writes for the reference's Interface (see there): the two dumps must be identical
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <string>
 #include <vector>
 #include "../../dnn-for-speech-enhancement_amd/csrc/host/pfile_reader.h"
 #include "../../dnn-for-speech-enhancement_amd/csrc/host/wts_io.h"
@@ -32,6 +36,63 @@ int main(int argc, char **argv)
             fwrite(&n, 4, 1, o);
             fwrite(in.data(), 4, (size_t)n * rc.input_dim, o);
             fwrite(tg.data(), 4, (size_t)n * rc.out_dim, o);
+        }
+        fclose(o);
+        return 0;
+    }
+    if (argc > 3 && !strcmp(argv[1], "epoch")) {
+        std::map<std::string, std::string> a;
+        for (int i = 3; i < argc; ++i) { const char *eq = strchr(argv[i], '='); if (eq) a[std::string(argv[i], eq - argv[i])] = eq + 1; }
+        auto geti = [&](const char *k) { return atoi(a[k].c_str()); };
+        auto getf = [&](const char *k, float d) { return a.count(k) ? (float)atof(a[k].c_str()) : d; };
+        int ls[16] = {0}, L = 0;
+        { const std::string v = a["layersizes"]; size_t pos = 0;
+          while (L < 10) { const size_t c = v.find(',', pos); ls[L++] = atoi(v.substr(pos, c == std::string::npos ? c : c - pos).c_str());
+                           if (c == std::string::npos) break; pos = c + 1; } }
+        bp::ReaderConfig rc;
+        rc.fea_file = a["fea_file"]; rc.targ_file = a["targ_file"]; rc.norm_file = a["norm_file"];
+        rc.fea_dim = geti("fea_dim"); rc.fea_context = geti("fea_context"); rc.targ_offset = geti("targ_offset");
+        rc.out_dim = ls[L - 1]; rc.traincache = geti("traincache"); rc.input_dim = ls[0];
+        FILE *o = fopen(argv[2], "wb");
+        auto put_i = [&](int v) { fwrite(&v, 4, 1, o); };
+        put_i(L); for (int i = 0; i < L; ++i) put_i(ls[i]);
+        // Interface::Initial order: norm file, srand48, initial weights (file or random)
+        std::vector<std::vector<float>> W(L), B(L);
+        float *w[16] = {0}, *b[16] = {0};
+        for (int i = 1; i < L; ++i) { W[i].assign((size_t)ls[i] * ls[i - 1], 0.f); B[i].assign(ls[i], 0.f); w[i] = W[i].data(); b[i] = B[i].data(); }
+        bp::PfileReader r(rc);
+        srand48(geti("init_randem_seed"));
+        if (a["initwts_file"].empty()) bp::random_weights(L, ls, w, b, getf("init_randem_weight_min", -0.1f), getf("init_randem_weight_max", 0.1f),
+                                                          getf("init_randem_bias_min", -0.1f), getf("init_randem_bias_max", 0.1f));
+        else { FILE *fi = fopen(a["initwts_file"].c_str(), "rb"); const std::string err = bp::read_weights(fi, L, ls, w, b); fclose(fi);
+               if (!err.empty()) { printf("%s\n", err.c_str()); return 3; } }
+        r.open();
+        put_i((int)r.total_frames()); put_i((int)r.total_sents());
+        fwrite(r.frames_before_sent().data(), 4, r.total_sents(), o);
+        auto range = [&](const char *k, int *st, int *en) { const std::string v = a[k]; const size_t d = v.find('-');
+                                                            *st = atoi(v.substr(0, d).c_str()); *en = atoi(v.substr(d + 1).c_str()); };
+        int st, en;
+        range("train_sent_range", &st, &en);
+        const bp::PfileReader::Plan tp = r.plan(st, en);
+        const int n = (int)tp.chunk_frame_st.size();
+        put_i(n); put_i((int)tp.total_samples); fwrite(tp.chunk_frame_st.data(), 4, n, o);
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        bp::PfileReader::rand_index(order.data(), n);
+        fwrite(order.data(), 4, n, o);
+        std::vector<float> in((size_t)rc.traincache * rc.input_dim), tg((size_t)rc.traincache * rc.out_dim);
+        for (int i = 0; i < n; ++i) {
+            const int cnt = r.read_chunk(tp, order[i], true, in.data(), tg.data());
+            put_i(cnt); fwrite(in.data(), 4, (size_t)cnt * rc.input_dim, o); fwrite(tg.data(), 4, (size_t)cnt * rc.out_dim, o);
+        }
+        { FILE *fw = fopen(a["outwts_file"].c_str(), "wb"); bp::write_weights(fw, L, ls, w, b); fclose(fw); }
+        range("cv_sent_range", &st, &en);
+        const bp::PfileReader::Plan cp = r.plan(st, en);
+        const int nc = (int)cp.chunk_frame_st.size();
+        put_i(nc); put_i((int)cp.total_samples); fwrite(cp.chunk_frame_st.data(), 4, nc, o);
+        for (int i = 0; i < nc; ++i) {
+            const int cnt = r.read_chunk(cp, i, false, in.data(), tg.data());
+            put_i(cnt); fwrite(in.data(), 4, (size_t)cnt * rc.input_dim, o); fwrite(tg.data(), 4, (size_t)cnt * rc.out_dim, o);
         }
         fclose(o);
         return 0;
