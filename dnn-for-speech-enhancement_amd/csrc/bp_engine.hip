@@ -689,7 +689,8 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
     if (n < 0 || n > h->cap) return fail(BP_ERR_ARG, std::string(who) + ": n_samples exceeds chunk capacity");
     if (D < 1 || ctx < 1 || c->n_frames < 0) return fail(BP_ERR_ARG, std::string(who) + ": bad fea_dim / context / n_frames");
     const bool nat = c->nat != nullptr;
-    if ((long)ctx * D + (nat ? D : 0) != (long)h->s[0])
+    // (a chunk may legitimately hold 0 samples -- the planner's last chunk, Interface.cc:607-614 -- and then carries no tables)
+    if (n > 0 && (long)ctx * D + (nat ? D : 0) != (long)h->s[0])
         return fail(BP_ERR_ARG, std::string(who) + ": layersizes[0] != context*fea_dim (+ fea_dim with a NAT block)");
     if (n > 0 && (!c->fea || !c->win_start || (with_targ && (!c->targ_frames || !c->targ_frame)) ||
                   (nat && (!c->nat_row || c->n_nat < 1))))

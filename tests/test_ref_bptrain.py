@@ -40,7 +40,7 @@ def test_reference_main_and_bptrain_write_identical_files(tmp_path, name, drop):
     outs = {}
     for who, exe in (("ref", REF_EXE), ("ours", OUR_EXE)):
         td = str(tmp_path / who); os.makedirs(td)
-        args = _inputs(td, name)
+        args = _set(_inputs(td, name), lrate="0.05")          # (the fixture's lrate=1 diverges on this random net)
         env = dict(os.environ)
         if drop:                                    # dropout on: same Philox key for both (the reference seeds from time())
             args = _set(args, dropoutflag=1, visible_omit=0.1, hid_omit=0.2)
@@ -60,7 +60,7 @@ def test_reference_main_and_bptrain_write_identical_files(tmp_path, name, drop):
             continue
         assert line in ours_lines, "reference log line missing from bptrain's log: %r" % line
     cv = [re.search(r"CV over\. squared error: (\S+)", o[1]).group(1) for o in (outs["ref"], outs["ours"])]
-    assert cv[0] == cv[1]
+    assert cv[0] == cv[1] and np.isfinite(float(cv[0]))
 
 
 def test_bptrain_gpu_used_2_trains_data_parallel(tmp_path, oracle_mod):
