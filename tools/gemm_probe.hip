@@ -6,10 +6,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <functional>
 #include <string>
 #include <vector>
 #include "../dnn-for-speech-enhancement_amd/csrc/bp_kernels.h"
+#include "wgrad_glds_probe.h"
 
 template <int NACC>
 __global__ __launch_bounds__(256) void mfma_peak(float *out, int iters)
@@ -98,10 +100,41 @@ int main(int argc, char **argv)
     WGR(128, 128, 16, 2, 2, 1, 0); WGR(128, 128, 16, 2, 2, 1, 128);
 #define WGS(BM, BN, BK, WM, WN, NT) vs.push_back({"wgrad " #BM "x" #BN "x" #BK " w" #WM "x" #WN " static" #NT " grid0", [&](hipStream_t s) { GemmArgs g; EpiArgs e; wg_args(g, e); go<BM, BN, BK, WM, WN, false, false, EPI_WGRAD_UPDATE, 1, NT>(s, g, e, H, H, 0); }, 2.0 * H * H * (double)KW})
     WGS(64, 64, 64, 2, 2, 4); WGS(128, 64, 16, 2, 2, 16); WGS(64, 64, 32, 2, 2, 8); WGS(64, 64, 16, 2, 2, 16); WGS(64, 128, 16, 2, 2, 16); WGS(128, 64, 32, 2, 2, 8); WGS(128, 128, 16, 2, 2, 16);
+    // LDS-DMA staged wgrad+update (bp_wgrad_glds.h), one 2048x2048 problem
+    vs.push_back({"wgrad glds 64x64x32 3-stage", [&](hipStream_t s) { MultiArgs a; memset(&a, 0, sizeof(a)); wg_args(a.g[0], a.e[0]);
+        a.g[0].tiles_m = H / 64; a.g[0].tiles_n = H / 64; a.first_tile[0] = 0; a.first_tile[1] = a.g[0].tiles_m * a.g[0].tiles_n; a.n = 1;
+        hipLaunchKernelGGL(bp_wgrad_glds_multi<1>, dim3(a.first_tile[1]), dim3(256), 0, s, a); }, 2.0 * H * H * (double)KW});
+    vs.push_back({"wgrad glds 128x64x16 3-stage", [&](hipStream_t s) { MultiArgs a; memset(&a, 0, sizeof(a)); wg_args(a.g[0], a.e[0]);
+        a.g[0].tiles_m = H / 128; a.g[0].tiles_n = H / 64; a.first_tile[0] = 0; a.first_tile[1] = a.g[0].tiles_m * a.g[0].tiles_n; a.n = 1;
+        hipLaunchKernelGGL(bp_wgrad_glds_multi<2>, dim3(a.first_tile[1]), dim3(256), 0, s, a); }, 2.0 * H * H * (double)KW});
+    // short-kernel MFMA shapes: G workgroups x 4 waves x N MFMAs per wave, NACC chains (what a 64x64x256 wgrad tile issues: 128 per wave)
+#define SHAPE(G, N, NACC) vs.push_back({"mfma shape G" #G " n" #N " chains" #NACC, [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<NACC>, dim3(G), dim3(256), 0, s, Yo, N / NACC); }, (double)G * 4 * N * 4096.0})
+    SHAPE(1024, 128, 2); SHAPE(768, 128, 2); SHAPE(256, 128, 2); SHAPE(1024, 128, 4); SHAPE(1024, 128, 1); SHAPE(256, 512, 2); SHAPE(3648, 128, 2); SHAPE(2048, 128, 2);
     // calibration: what the matrix pipe delivers on this box (one wave per SIMD, 256 workgroups)
     vs.push_back({"mfma peak: 1 dependent chain/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<1>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0});
     vs.push_back({"mfma peak: 4 chains/wave", [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<4>, dim3(256), dim3(256), 0, s, Yo, 512); }, 256.0 * 4 * 512 * 4096.0 * 4});
 
+    if (getenv("PROBE_CHECK")) {
+        const size_t nW = (size_t)H * LD;
+        std::vector<float> w0(nW), r1(nW), r2(nW), d1(nW), d2(nW), b1(H), b2(H);
+        CK(hipMemcpy(w0.data(), W, nW * 4, hipMemcpyDeviceToHost));
+        for (int which = 0; which < 2; ++which) {
+            CK(hipMemcpy(W, w0.data(), nW * 4, hipMemcpyHostToDevice)); CK(hipMemset(D, 0, nW * 4)); CK(hipMemset(bias, 0, H * 4)); CK(hipMemset(bd, 0, H * 4));
+            GemmArgs g; EpiArgs e; wg_args(g, e); e.c1 = 0.5f; e.wc = 0.01f;
+            if (which == 0) go<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE, 1, 8>(st, g, e, H, H, 0);
+            else { MultiArgs a; memset(&a, 0, sizeof(a)); a.g[0] = g; a.e[0] = e; a.g[0].tiles_m = H / 128; a.g[0].tiles_n = H / 64; a.first_tile[1] = (H / 128) * (H / 64); a.n = 1;
+                   hipLaunchKernelGGL(bp_wgrad_glds_multi<2>, dim3(a.first_tile[1]), dim3(256), 0, st, a); }
+            CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(which ? r2.data() : r1.data(), W, nW * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(which ? d2.data() : d1.data(), D, nW * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(which ? b2.data() : b1.data(), bias, H * 4, hipMemcpyDeviceToHost));
+        }
+        double mw = 0, md = 0, mb = 0, sw = 0, sd = 0, sb = 0;
+        for (size_t i = 0; i < nW; ++i) { mw = std::max(mw, (double)fabsf(r1[i] - r2[i])); md = std::max(md, (double)fabsf(d1[i] - d2[i])); sw = std::max(sw, (double)fabsf(r1[i] - w0[i])); sd = std::max(sd, (double)fabsf(d1[i])); }
+        for (int i = 0; i < H; ++i) { mb = std::max(mb, (double)fabsf(b1[i] - b2[i])); sb = std::max(sb, (double)fabsf(b1[i])); }
+        printf("CHECK glds vs static8: max|dW| %.3e (update size %.3e)  max|dDelta| %.3e (|delta| %.3e)  max|dbias| %.3e (|bias| %.3e)\n", mw, sw, md, sd, mb, sb);
+        CK(hipMemcpy(W, w0.data(), nW * 4, hipMemcpyHostToDevice)); CK(hipMemset(D, 0, nW * 4));
+    }
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int lds[] = {2048, 2112, 2176, 2304};
     const int nld = getenv("PROBE_LDS") ? 4 : 1;
