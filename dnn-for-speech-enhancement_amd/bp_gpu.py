@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_dp_forward_layer", "bp_dp_dgrads", "bp_dp_wgrad_layer", "bp_apply_update_layer", "bp_advance_step",
     "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
     "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
-    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info", "bp_profile_step", "bp_measure_peaks", "bp_device_count",
+    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info", "bp_profile_step", "bp_measure_peaks", "bp_device_count", "bp_train_resident_masked", "bp_forward_windows",
 ]
 PROF_KINDS = ["fwd_l1", "fwd_hidden", "fwd_out", "dgrad_out", "dgrad_hidden", "wgrad_update_grouped"]
 
@@ -92,6 +92,7 @@ def load_library(path=None):
     lib.bp_upload_chunk_windows.argtypes = [hp, C.POINTER(BPWindowChunk)]
     lib.bp_train_chunk_windows.argtypes = [hp, C.POINTER(BPWindowChunk)]
     lib.bp_cv_chunk_windows.argtypes = [hp, C.POINTER(BPWindowChunk), fp]
+    lib.bp_forward_windows.argtypes = [hp, C.POINTER(BPWindowChunk), fp]
     lib.bp_fill_chunk_synthetic.argtypes = [hp, C.c_int, C.c_uint64]
     lib.bp_train_resident.argtypes = [hp, C.c_int, C.c_int]
     lib.bp_sync.argtypes = [hp]
@@ -113,6 +114,7 @@ def load_library(path=None):
     lib.bp_set_stream.argtypes = [hp, C.c_void_p]
     lib.bp_last_train_ms.argtypes = [hp, fp, C.POINTER(C.c_int)]
     lib.bp_time_kernel.argtypes = [hp, C.c_int, C.c_int, fp]
+    lib.bp_train_resident_masked.argtypes = [hp, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8))]
     lib.bp_profile_step.argtypes = [hp, C.c_int, C.c_int, fp, C.POINTER(C.c_int)]
     lib.bp_measure_peaks.argtypes = [hp, fp, fp]
     lib.bp_set_hyper.argtypes = [hp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
@@ -288,6 +290,18 @@ class BP_GPU(object):
 
     def train_resident(self, first_frame, n_frames):
         self._check(self._lib.bp_train_resident(self._h, int(first_frame), int(n_frames)))
+
+    def train_resident_masked(self, first_frame, n_frames, masks):
+        """masks[l], l = 0..numlayers-2: uint8 [n_frames][layersizes[l]] (1 = drop) or None -- parity tests only."""
+        P = C.POINTER(C.c_uint8)
+        arr = (P * MAXLAYER)()
+        keep = []
+        for l, m in enumerate(masks):
+            if m is not None:
+                m = np.ascontiguousarray(m, dtype=np.uint8).reshape(int(n_frames), self.layersizes[l])
+                keep.append(m)
+                arr[l] = m.ctypes.data_as(P)
+        self._check(self._lib.bp_train_resident_masked(self._h, int(first_frame), int(n_frames), arr))
 
     def grads_resident(self, first_frame):
         self._check(self._lib.bp_grads_resident(self._h, int(first_frame)))

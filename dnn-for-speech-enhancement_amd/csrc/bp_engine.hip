@@ -54,11 +54,15 @@ struct bp_handle {
     float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
     struct bp_dp *dp;            // attached data-parallel group (bp_dp_attach) or null
     struct StepProf *prof;       // bp_profile_step in progress: an event after every launch of the step
+    const uint8_t *inj_mask[BP_MAXLAYER];   // bp_train_resident_masked in progress: device masks of this bunch per layer output
+    const float *inj_x0;                    // ... and the masked copy of its input rows
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
     float *in, *in_drop, *targ, *out_dev;
     float *slabs; size_t slab_stride; int out_splits;   // split-K workspace of the output layer
     float *grad; size_t grad_floats; size_t g_off[BP_MAXLAYER], g_cnt[BP_MAXLAYER];
-    float *host_out;             // pinned staging for CV outputs
+    float *host_out;             // pinned staging for CV outputs (grow-only, whole chunk)
+    float *out_chunk;            // device: network outputs of a whole chunk [frames][ld_L] (CV / forward), grow-only
+    size_t out_chunk_frames;
     uint32_t step;               // bunches trained so far (dropout stream position)
     int dp_first, dp_next_layer, dp_fwd_next; // layer-by-layer data-parallel step in progress
     long mask_lo, mask_hi; uint32_t mask_step0;
@@ -150,6 +154,7 @@ extern "C" int bp_destroy(bp_handle *h)
     if (h->ev_retired) (void)hipEventDestroy(h->ev_retired);
     if (h->ev_staging) (void)hipEventDestroy(h->ev_staging);
     if (h->host_out) (void)hipHostFree(h->host_out);
+    if (h->out_chunk) (void)hipFree(h->out_chunk);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -224,7 +229,6 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
         h->slab_stride = Bp * h->ld[L - 1];
         CK(dev_alloc(h, &h->slabs, h->slab_stride * h->out_splits));
     }
-    HK(hipHostMalloc((void **)&h->host_out, (size_t)h->B * h->ld[L - 1] * sizeof(float)));
     size_t goff = 0;
     for (int l = 1; l < L; ++l) {
         const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
@@ -339,6 +343,7 @@ static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const f
         e.drop_thresh = train ? h->th_hid : 0u;
         e.seed_lo = (uint32_t)h->cfg.seed; e.seed_hi = (uint32_t)(h->cfg.seed >> 32);
         e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
+        if (train && h->inj_mask[l]) { e.mask = h->inj_mask[l]; e.ldmask = h->s[l]; e.drop_thresh = 1u; }   // injected mask (tests)
         if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
         if (l == 1) return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1, 1>(st, g, e, M, cur);   // (own name in profiles)
         return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
@@ -601,7 +606,8 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
     const float *x0 = h->in + (size_t)first * h->ld[0];
-    if (use_mask(h)) {
+    if (h->inj_x0) x0 = h->inj_x0;                      // bp_train_resident_masked: input rows with the injected visible mask
+    else if (use_mask(h)) {
         const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
                         (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
                         (first - h->mask_lo) % B == 0;
@@ -822,6 +828,58 @@ extern "C" int bp_train_chunk_windows(bp_handle *h, const bp_window_chunk *c)
     if (c->n_samples % h->B)
         printf("this bunch has only %d samples and is ignored.\n", c->n_samples % h->B);   // BP_GPU.cu:317
     return bp_train_resident(h, 0, c->n_samples);
+}
+
+
+// Parity-test entry (no reference counterpart; the reference's masks come from cuRAND seeded by time(NULL),
+// BP_GPU.cu:77-78,534-551): the bunch loop of bp_train_resident with CALLER-SUPPLIED dropout masks instead of the
+// Philox stream, so that fixtures with stored masks (tests/golden/*dropout*.npz, computed in fp64) can be trained
+// on the device.  masks[l], l = 0..numlayers-2: host array [n_frames][layersizes[l]] of bytes, 1 = drop the output
+// of layer l for that frame (l = 0: the input frame), or NULL for no dropout on that layer.  fp32 single-device only.
+extern "C" int bp_train_resident_masked(bp_handle *h, int first_frame, int n_frames, const uint8_t *const *masks)
+{
+    if (!h || !masks) return fail(BP_ERR_ARG, "bp_train_resident_masked: null argument");
+    if (h->bf || h->dp || h->Bg != h->B) return fail(BP_ERR_STATE, "bp_train_resident_masked: fp32 single-device handles only");
+    if (first_frame < 0 || n_frames < 0 || first_frame + n_frames > h->chunk_frames)
+        return fail(BP_ERR_ARG, "bp_train_resident_masked: frame range outside the resident chunk");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int L = h->L, B = h->B, nb = n_frames / B;
+    uint8_t *dm[BP_MAXLAYER] = {nullptr};
+    float *xm = nullptr;
+    int rc = BP_OK;
+    hipError_t er = hipSuccess;
+    for (int l = 0; l < L - 1 && er == hipSuccess; ++l) {
+        if (!masks[l]) continue;
+        const size_t bytes = (size_t)nb * B * h->s[l];
+        er = hipMalloc((void **)&dm[l], bytes ? bytes : 1);
+        if (er == hipSuccess) er = hipMemcpyAsync(dm[l], masks[l], bytes, hipMemcpyHostToDevice, h->stream);
+    }
+    if (er == hipSuccess && dm[0]) er = hipMalloc((void **)&xm, ((size_t)B + 64) * h->ld[0] * sizeof(float) + SLACK * sizeof(float));
+    if (er == hipSuccess && xm) er = hipMemsetAsync(xm, 0, ((size_t)B + 64) * h->ld[0] * sizeof(float) + SLACK * sizeof(float), h->stream);
+    for (int i = 0; i < nb && er == hipSuccess; ++i) {
+        const int first = first_frame + i * B;
+        if (dm[0]) {
+            hipLaunchKernelGGL(bp_apply_mask, dim3((h->ld[0] + 255) / 256, B), dim3(256), 0, h->stream, h->in + (size_t)first * h->ld[0], xm,
+                               h->ld[0], h->s[0], dm[0] + (size_t)i * B * h->s[0], B);
+            er = hipGetLastError();
+            h->inj_x0 = xm;
+        }
+        for (int l = 1; l < L - 1; ++l) h->inj_mask[l] = dm[l] ? dm[l] + (size_t)i * B * h->s[l] : nullptr;
+        // with injected masks the Philox thresholds must stay out of the way: layers without a mask get no dropout
+        const uint32_t th_hid = h->th_hid, th_vis = h->th_vis;
+        h->th_hid = 0u; h->th_vis = 0u;
+        if (er == hipSuccess) er = bunch(h, first, true);
+        h->th_hid = th_hid; h->th_vis = th_vis;
+        h->step++;
+        if (er == hipSuccess) er = hipStreamSynchronize(h->stream);     // (xm is reused by the next bunch)
+    }
+    h->inj_x0 = nullptr;
+    for (int l = 0; l < BP_MAXLAYER; ++l) h->inj_mask[l] = nullptr;
+    if (er != hipSuccess) rc = fail(BP_ERR_DEVICE, std::string("bp_train_resident_masked: ") + hipGetErrorString(er));
+    (void)hipStreamSynchronize(h->stream);
+    for (auto p : dm) if (p) (void)hipFree(p);
+    if (xm) (void)hipFree(xm);
+    return rc;
 }
 
 // ------------------------------------------------------------------ data-parallel split
@@ -1331,18 +1389,51 @@ extern "C" int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibat
 }
 
 // ------------------------------------------------------------------ inference / CV
+// Outputs of a whole chunk stay on the device until ONE device-to-host copy at the end (the reference copies and
+// synchronises per bunch and cudaMallocs per call, BP_GPU.cu:699,762-763).
+static int out_chunk_reserve(bp_handle *h, int n_frames)
+{
+    if ((size_t)n_frames <= h->out_chunk_frames) return BP_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->out_chunk) { (void)hipFree(h->out_chunk); h->out_chunk = nullptr; }
+    if (h->host_out) { (void)hipHostFree(h->host_out); h->host_out = nullptr; }
+    h->out_chunk_frames = 0;
+    const size_t want = (size_t)n_frames + (size_t)n_frames / 4 + 64;
+    const size_t bytes = want * h->ld[h->L - 1] * sizeof(float);
+    if (hipMalloc((void **)&h->out_chunk, bytes + SLACK * sizeof(float)) != hipSuccess) return fail(BP_ERR_NOMEM, "hipMalloc (chunk outputs)");
+    if (hipHostMalloc((void **)&h->host_out, bytes) != hipSuccess) return fail(BP_ERR_NOMEM, "hipHostMalloc (chunk outputs)");
+    h->out_chunk_frames = want;
+    return BP_OK;
+}
+
+// forward of frames [first, first+fb) of the resident chunk with CV semantics; output rows go to out_chunk[first ..]
 static int forward_bunch(bp_handle *h, int first, int fb)
 {
     const int L = h->L;
     const float vis_keep = 1.0f - h->cfg.visible_omit, hid_keep = 1.0f - h->cfg.hid_omit;   // BP_GPU.cu:703-704
+    float *out = h->out_chunk + (size_t)first * h->ld[L - 1];
     if (h->bf) HIPCHK(bf_input(h, h->in + (size_t)first * h->ld[0], fb));
     for (int l = 1; l < L; ++l) {
         float alpha = 1.0f;
         if (h->cfg.dropoutflag == 1) alpha = (l == 1) ? vis_keep : hid_keep;
-        if (h->bf) { HIPCHK(bf_fwd(h, l, fb, nullptr, h->out_dev, false, alpha)); continue; }
+        if (h->bf) { HIPCHK(bf_fwd(h, l, fb, nullptr, out, false, alpha)); continue; }
         const float *yp = (l == 1) ? h->in + (size_t)first * h->ld[0] : h->y[l - 1];
-        HIPCHK(launch_fwd(h, h->stream, l, fb, yp, nullptr, h->out_dev, false, alpha));
+        HIPCHK(launch_fwd(h, h->stream, l, fb, yp, nullptr, out, false, alpha));
     }
+    return BP_OK;
+}
+
+// every bunch of the resident chunk (partial last bunch included, BP_GPU.cu:450-453), then one copy into host_out
+static int forward_chunk(bp_handle *h, int n)
+{
+    int r = out_chunk_reserve(h, n);
+    if (r != BP_OK) return r;
+    for (int i = 0; i < n; i += h->B) {
+        const int fb = h->B > n - i ? n - i : h->B;
+        if ((r = forward_bunch(h, i, fb)) != BP_OK) return r;
+    }
+    if (n > 0) HIPCHK(hipMemcpyAsync(h->host_out, h->out_chunk, (size_t)n * h->ld[h->L - 1] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return BP_OK;
 }
 
@@ -1351,15 +1442,20 @@ extern "C" int bp_forward(bp_handle *h, int n_frames, const float *in, float *ou
     if (!h || !in || !out) return fail(BP_ERR_ARG, "bp_forward: null argument");
     int r = bp_upload_chunk(h, n_frames, in, nullptr);
     if (r != BP_OK) return r;
-    const int L = h->L, sL = h->s[L - 1], ldL = h->ld[L - 1];
-    for (int i = 0; i < n_frames; i += h->B) {
-        const int fb = h->B > n_frames - i ? n_frames - i : h->B;
-        r = forward_bunch(h, i, fb);
-        if (r != BP_OK) return r;
-        HIPCHK(hipMemcpy2DAsync(out + (size_t)i * sL, (size_t)sL * 4, h->out_dev, (size_t)ldL * 4, (size_t)sL * 4, fb,
-                                hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
+    if ((r = forward_chunk(h, n_frames)) != BP_OK) return r;
+    const int sL = h->s[h->L - 1], ldL = h->ld[h->L - 1];
+    for (int j = 0; j < n_frames; ++j) memcpy(out + (size_t)j * sL, h->host_out + (size_t)j * ldL, sizeof(float) * sL);
+    return BP_OK;
+}
+
+extern "C" int bp_forward_windows(bp_handle *h, const bp_window_chunk *c, float *out)
+{
+    if (!out) return fail(BP_ERR_ARG, "bp_forward_windows: null argument");
+    int r = upload_windows(h, c, false, "bp_forward_windows");
+    if (r != BP_OK) return r;
+    if ((r = forward_chunk(h, c->n_samples)) != BP_OK) return r;
+    const int sL = h->s[h->L - 1], ldL = h->ld[h->L - 1];
+    for (int j = 0; j < c->n_samples; ++j) memcpy(out + (size_t)j * sL, h->host_out + (size_t)j * ldL, sizeof(float) * sL);
     return BP_OK;
 }
 
@@ -1368,21 +1464,14 @@ extern "C" int bp_cv_chunk(bp_handle *h, int n_frames, const float *in, const fl
     if (!h || !in || !targ || !sq_err_sum) return fail(BP_ERR_ARG, "bp_cv_chunk: null argument");
     int r = bp_upload_chunk(h, n_frames, in, nullptr);
     if (r != BP_OK) return r;
-    const int L = h->L, sL = h->s[L - 1], ldL = h->ld[L - 1];
+    if ((r = forward_chunk(h, n_frames)) != BP_OK) return r;
+    const int sL = h->s[h->L - 1], ldL = h->ld[h->L - 1];
     float squared_err = 0.0f;
-    for (int i = 0; i < n_frames; i += h->B) {          // partial bunch processed (BP_GPU.cu:450-453)
-        const int fb = h->B > n_frames - i ? n_frames - i : h->B;
-        r = forward_bunch(h, i, fb);
-        if (r != BP_OK) return r;
-        HIPCHK(hipMemcpyAsync(h->host_out, h->out_dev, (size_t)fb * ldL * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        const float *t = targ + (size_t)i * sL;
-        for (int j = 0; j < fb; ++j)                     // fp32, frame-major / bin-minor (BP_GPU.cu:458-467)
-            for (int d = 0; d < sL; ++d) {
-                const float e = h->host_out[(size_t)j * ldL + d] - t[(size_t)j * sL + d];
-                squared_err = squared_err + e * e;
-            }
-    }
+    for (int j = 0; j < n_frames; ++j)                   // fp32, frame-major / bin-minor (BP_GPU.cu:458-467)
+        for (int d = 0; d < sL; ++d) {
+            const float e = h->host_out[(size_t)j * ldL + d] - targ[(size_t)j * sL + d];
+            squared_err = squared_err + e * e;
+        }
     *sq_err_sum = squared_err;
     return BP_OK;
 }
@@ -1396,19 +1485,13 @@ extern "C" int bp_cv_chunk_windows(bp_handle *h, const bp_window_chunk *c, float
     if (n > 0 && (!c->targ_frames || !c->targ_frame)) return fail(BP_ERR_ARG, "bp_cv_chunk_windows: null targets");
     for (int i = 0; i < n; ++i)
         if (c->targ_frame[i] < 0 || c->targ_frame[i] >= c->n_frames) return fail(BP_ERR_ARG, "bp_cv_chunk_windows: targ_frame out of range");
+    if ((r = forward_chunk(h, n)) != BP_OK) return r;
     float squared_err = 0.0f;
-    for (int i = 0; i < n; i += h->B) {                  // partial bunch processed (BP_GPU.cu:450-453)
-        const int fb = h->B > n - i ? n - i : h->B;
-        r = forward_bunch(h, i, fb);
-        if (r != BP_OK) return r;
-        HIPCHK(hipMemcpyAsync(h->host_out, h->out_dev, (size_t)fb * ldL * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        for (int j = 0; j < fb; ++j) {                   // fp32, frame-major / bin-minor (BP_GPU.cu:458-467)
-            const float *t = c->targ_frames + (size_t)c->targ_frame[i + j] * sL;
-            for (int d = 0; d < sL; ++d) {
-                const float e = h->host_out[(size_t)j * ldL + d] - t[d];
-                squared_err = squared_err + e * e;
-            }
+    for (int j = 0; j < n; ++j) {                        // fp32, frame-major / bin-minor (BP_GPU.cu:458-467)
+        const float *t = c->targ_frames + (size_t)c->targ_frame[j] * sL;
+        for (int d = 0; d < sL; ++d) {
+            const float e = h->host_out[(size_t)j * ldL + d] - t[d];
+            squared_err = squared_err + e * e;
         }
     }
     *sq_err_sum = squared_err;

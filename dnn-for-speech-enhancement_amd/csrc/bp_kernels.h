@@ -70,6 +70,8 @@ struct EpiArgs {
     // dropout of the produced activation (BP_GPU.cu:546-549 applied by the producer)
     uint32_t drop_thresh, seed_lo, seed_hi, step, layer;
     int frame_off;                   // global frame index of row 0 of this bunch
+    const uint8_t *mask; int ldmask; // injected dropout mask of the produced activation ([row][unit] bytes, 1 = drop;
+                                     // bp_train_resident_masked, parity tests only) -- replaces the Philox draw
 };
 
 // ------------------------------------------------------------------ Philox4x32-10
@@ -294,7 +296,10 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
         for (int q = R0 / 4; q < (R0 + RN) / 4; ++q) {
             uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             const int r0 = rbase + 8 * q;
-            if (e.drop_thresh) drop_words4(w, r0, n, e.frame_off, (uint32_t)e.n_true, e.layer, e.step, e.seed_lo, e.seed_hi);
+            if (e.mask) {                                        // injected mask: word 0 = "drop", thresh 1 (set by the host)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (r0 + j < e.m_limit && live && e.mask[(size_t)(r0 + j) * e.ldmask + n]) ? 0u : 0xFFFFFFFFu;
+            } else if (e.drop_thresh) drop_words4(w, r0, n, e.frame_off, (uint32_t)e.n_true, e.layer, e.step, e.seed_lo, e.seed_hi);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int m = r0 + j;
@@ -956,6 +961,16 @@ __global__ void bp_mask_input(const float *in, float *out, int ld, int width, in
         }
         out[(size_t)f * ld + u] = v;
     }
+}
+
+// Injected visible-layer mask (bp_train_resident_masked, parity tests): out[f][u] = mask[f][u] ? 0 : in[f][u]
+__global__ void bp_apply_mask(const float *in, float *out, int ld, int width, const uint8_t *mask, int n_frames)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (u >= ld || f >= n_frames) return;
+    float v = in[(size_t)f * ld + u];
+    if (u < width && mask[(size_t)f * width + u]) v = 0.0f;
+    out[(size_t)f * ld + u] = v;
 }
 
 // Synthetic N(0,1) fill of a padded [rows][ld] buffer (cols >= width stay 0): Philox + Box-Muller.

@@ -180,6 +180,11 @@ int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowC
     if (fread(raw.data(), sizeof(float) * (D + 2), frames_need, fp_data_) != (size_t)frames_need)
         die("data pfile: short read in chunk %d.", ci);
     const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
+    // The id indexes the sentence table below.  The reference trusts it; a corrupt or mismatched Pfile would make us read
+    // outside the table (or silently build wrong windows), so it must lie in the planned range and own the chunk's first frame.
+    if (first_sent < p.sent_st || first_sent > p.sent_en || first_sent >= (int)total_sents_ || frames_before_sent_[first_sent] <= frame_st ||
+        (first_sent > 0 && frames_before_sent_[first_sent - 1] > frame_st))
+        die("data pfile: record %d carries sentence id %d, which does not contain that frame (sentences %d-%d planned).", frame_st, first_sent, p.sent_st, p.sent_en);
     w.fea.resize((size_t)frames_need * D);
     parallel_rows(frames_need, [&](int lo, int hi) {
         for (int i = lo; i < hi; ++i)
@@ -236,7 +241,10 @@ int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowC
                 w.nat_row[pos] = nat_id;
             }
             int tf = frames_processed + j + cfg_.targ_offset;
-            if (tf >= frames_need) tf = frames_need - 1;
+            if (tf >= frames_need) {                     // (the reference reads past its buffer here)
+                if (!clamp_warned_) { fprintf(stderr, "pfile_reader: targ_offset %d points past the chunk's last frame; clamped (check targ_offset)\n", cfg_.targ_offset); clamp_warned_ = true; }
+                tf = frames_need - 1;
+            }
             w.targ_frame[pos] = tf;
             ++cur_sample;
         }

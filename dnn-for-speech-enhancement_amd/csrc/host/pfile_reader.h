@@ -3,9 +3,10 @@
 // frames + targets, exactly what the reference's Interface feeds to BP_GPU::train / CrossValid
 // (Interface.cc:468-1034, restated from its behaviour; formats in SURVEY.md Appendix B).
 //
-// Parity note: Interface.cc cannot be compiled in this image (it includes BP_GPU.h -> CUDA headers),
-// so this reader is pinned by an independent numpy restatement (tests/test_pfile_reader.py) and
-// not by reference-generated fixtures.
+// Parity: pinned BYTE FOR BYTE to the reference's own Interface.cc, which compiles in the build container once its
+// `#include "BP_GPU.h"` resolves to this repo's drop-in header (`make -C oracle ref`): reference-generated
+// fixtures tests/golden/ref/*.npz + tests/test_ref_pins.py (plan, chunk order, every chunk's indata/targ, .wts bytes),
+// and additionally by the independent numpy restatement tests/pfile_util.py (tests/test_pfile_reader.py).
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -65,6 +66,7 @@ private:
     std::vector<float> mean_, dvar_;
     std::vector<uint32_t> raw_;       // file-record scratch, kept across chunks
     bool nat_ = false;
+    bool clamp_warned_ = false;
 };
 
 [[noreturn]] void die(const char *fmt, ...);   // message + exit(0), the reference's error convention

@@ -129,6 +129,11 @@ int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, const float *ta
 int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed); /* N(0,1) in/targ on device */
 int bp_train_resident(bp_handle *h, int first_frame, int n_frames);
 int bp_sync(bp_handle *h);
+/* Parity-test entry: bp_train_resident with CALLER-SUPPLIED dropout masks instead of the Philox stream (the reference's
+ * masks come from cuRAND seeded by time(NULL), BP_GPU.cu:77-78,534-551, so "same result given the same mask" is the
+ * parity statement).  masks[l], l = 0 .. numlayers-2: host [n_frames][layersizes[l]] bytes, 1 = drop the output of
+ * layer l for that frame (l = 0: the input frame); NULL = no dropout on that layer.  fp32 single-device handles. */
+int bp_train_resident_masked(bp_handle *h, int first_frame, int n_frames, const uint8_t *const *masks);
 
 /* ------------------------------------------------------------------------------------
  * On-device frame stacking.  The reference's reader materialises every
@@ -157,6 +162,7 @@ typedef struct bp_window_chunk {
 int bp_upload_chunk_windows(bp_handle *h, const bp_window_chunk *c);             /* then bp_train_resident etc. */
 int bp_train_chunk_windows(bp_handle *h, const bp_window_chunk *c);              /* = BP_GPU::train on the expanded chunk */
 int bp_cv_chunk_windows(bp_handle *h, const bp_window_chunk *c, float *sq_err_sum); /* = BP_GPU::CrossValid */
+int bp_forward_windows(bp_handle *h, const bp_window_chunk *c, float *out);         /* = bp_forward: out[n_samples][sL] (enhancement) */
 
 /* ------------------------------------------------------------------------------------
  * Data-parallel split of train_bunch_single (the reference's dead train_bunch_multi,

@@ -38,6 +38,26 @@ def test_golden_no_dropout_or_cv(pkg, name):
     g.close()
 
 
+@pytest.mark.parametrize("name", [n for n in golden_cases() if load_golden(n)["has_drop"]])
+def test_golden_dropout_training_with_injected_masks(pkg, name):
+    """The fp64 goldens that carry stored dropout masks, TRAINED on the device through the test-only masked entry
+    (bp_train_resident_masked): "same result given the same mask" is the parity statement for dropout, since the
+    reference seeds cuRAND from time(NULL) (BP_GPU.cu:77-78)."""
+    c = load_golden(name)
+    g = _mk(pkg, c["ls"], c["B"], c["W"], c["b"], lr=c["lr"], m=c["m"], wc=c["wc"], activation=c["act"], momentum_rule=c["rule"],
+            dropoutflag=1, visible_omit=c["drop"][0], hid_omit=c["drop"][1], cap=c["steps"] * c["B"])
+    x = np.concatenate(c["xs"]); t = np.concatenate(c["ts"])
+    g.upload_chunk(x, t)
+    masks = [np.concatenate([c["masks"][s][l] for s in range(c["steps"])]) for l in range(c["L"] - 1)]
+    g.train_resident_masked(0, x.shape[0], masks)
+    g.sync()
+    w, b = g.get_weights()
+    for l in range(1, c["L"]):
+        assert relerr(w[l], c["Wf"][l]) < TOL, (name, "W", l, relerr(w[l], c["Wf"][l]))
+        assert relerr(b[l], c["bf"][l]) < TOL, (name, "b", l, relerr(b[l], c["bf"][l]))
+    g.close()
+
+
 CASES = [
     # layersizes, B, n_bunches, activation, rule, wc, dropout
     ([12, 7, 5, 3], 4, 3, 0, 0, 0.0, False),
@@ -210,21 +230,31 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
     w, bb = g.get_weights()
     dw, dbb = g.get_deltas()
 
-    def close(a, r32, r64):
-        # 1e-4 relative, plus slack for quantities that are ill-conditioned in fp32 under ANY summation
-        # order: the bias gradient is a sum of 256 cancelling terms (biases start at 0 and stay ~1e-5),
-        # and at this size a handful of the 1.5 M hidden pre-activations per bunch sit within rounding of
-        # 0, so their ReLU on/off decision (hence one frame's contribution to a column of the ~1e-6
-        # momentum state) depends on the GEMM's summation order.  There the bar is "as close to the
-        # fp64-accumulated value as the fp32 restatement of the reference is"
-        ea = np.abs(np.asarray(a, np.float64) - r64).max()
-        e32 = np.abs(np.asarray(r32, np.float64) - r64).max()
-        return ea <= TOL * np.abs(r64).max() + 4.0 * e32
-
+    # (1) the contract of north_star is on OUTPUTS: the trained network's forward on fresh frames, plain 1e-4
+    xf = rng.standard_normal((300, ls[0]), dtype=np.float32)
+    og, o32f, o64f = g.forward(xf), o.forward(xf), o64.forward(xf)
+    e_out, e_ref = relerr(og, o32f), relerr(o32f, o64f)
+    print("forward output after 2 steps: rel.err vs fp32 oracle %.2e (fp32 oracle vs fp64-accumulated oracle: %.2e)" % (e_out, e_ref))
+    # plain 1e-4, or -- when a ReLU flip (see below) has pushed two correct fp32 trajectories apart by more than that --
+    # at least as close to the fp64-accumulated trajectory as the reference-order fp32 restatement is (x4)
+    assert e_out < TOL or np.abs(og.astype(np.float64) - o64f).max() <= TOL * np.abs(o64f).max() + 4.0 * np.abs(o32f.astype(np.float64) - o64f).max(), (e_out, e_ref)
+    # (2) state tensors: reported per tensor.  Plain 1e-4 where achieved; a tensor that misses it is bounded, BY NAME,
+    # against the fp64-accumulated oracle -- "as close to the exact value as the fp32 restatement of the reference is"
+    # (x4).  Why some miss: about one of the ~1.5 M hidden pre-activations per bunch lies within fp32 rounding of 0, its
+    # ReLU on/off decision then depends on the GEMM's summation order, and that one frame's contribution moves a whole
+    # column of G by ~1e-2 of max|delta| (~2e-4 of max|W|); biases start at 0 and stay ~1e-5, a sum of 256 cancelling terms.
+    worst, bounded = {}, []
     for l in range(1, len(ls)):
-        assert close(w[l], o.W[l], o64.W[l]) and relerr(w[l], o.W[l]) < 5 * TOL, l
-        assert close(dw[l], o.dW[l], o64.dW[l]), l
-        assert close(bb[l], o.b[l], o64.b[l]) and close(dbb[l], o.db[l], o64.db[l]), l
+        for nm, a, r32, r64 in (("W", w[l], o.W[l], o64.W[l]), ("b", bb[l], o.b[l], o64.b[l]),
+                                ("dW", dw[l], o.dW[l], o64.dW[l]), ("db", dbb[l], o.db[l], o64.db[l])):
+            e = relerr(a, r32)
+            worst["%s%d" % (nm, l)] = e
+            if not e < TOL:
+                ea = np.abs(np.asarray(a, np.float64) - r64).max()
+                e32 = np.abs(np.asarray(r32, np.float64) - r64).max()
+                bounded.append("%s%d" % (nm, l))
+                assert ea <= TOL * np.abs(r64).max() + 4.0 * e32, (nm, l, e, ea, e32)
+    print("rel.err vs fp32 oracle:", {k: "%.1e" % v for k, v in worst.items()}, "| bounded against fp64 instead:", bounded)
     g.close()
 
 

@@ -114,3 +114,61 @@ def test_dp_shards_sum_to_single_device(oracle_mod):
             sb[l] = sb[l] + b_[l].astype(np.float64)
     for l in (1, 2):
         assert relerr(sw[l], gw[l]) < 1e-6 and relerr(sb[l], gb[l]) < 1e-6
+
+
+@pytest.mark.parametrize("act,rule,wc,drop", [(0, 0, 0.0, True), (0, 1, 0.001, False), (1, 0, 0.01, True), (1, 1, 0.0, False)])
+def test_oracle_trajectory_matches_torch_fp64_at_1024_wide(oracle_mod, act, rule, wc, drop):
+    """Independent pin of the oracle beyond one gradient (the reference's CUDA path cannot run here and holds no goldens):
+    a multi-step TRAJECTORY on 1024-wide layers -- momentum, weight cost, both momentum rules, both activations, injected
+    dropout masks, the double 1/B (DevFunc.cu:263,317), then the CV forward with keep-scaled weights -- against torch
+    float64 autograd of (1/B) sum (out-t)^2 plus the update rule written out in tensor algebra."""
+    torch = pytest.importorskip("torch")
+    ls, B, steps, lr, m = [300, 1024, 1024, 64], 48, 3, 0.7, 0.6
+    pv, ph = 0.15, 0.25
+    W, b = N.glorot_net(ls, seed=21, beta=1.0)
+    rng = np.random.default_rng(5)
+    b = [None] + [rng.normal(size=ls[l]).astype(np.float32) * 0.1 for l in range(1, len(ls))]
+    L = len(ls)
+    o = oracle_mod.Oracle(ls, B, lr, m, wc, W, b, activation=act, momentum_rule=rule, acc_double=True,
+                          dropoutflag=1 if drop else 0, visible_omit=pv, hid_omit=ph)
+    tw = [None] + [torch.tensor(W[l], dtype=torch.float64) for l in range(1, L)]
+    tb = [None] + [torch.tensor(b[l], dtype=torch.float64) for l in range(1, L)]
+    dw = [None] + [torch.zeros_like(tw[l]) for l in range(1, L)]
+    db = [None] + [torch.zeros_like(tb[l]) for l in range(1, L)]
+    c1 = lr if rule == 1 else (1.0 - m) * lr
+    for s in range(steps):
+        x = rng.normal(size=(B, ls[0])).astype(np.float32)
+        t = rng.normal(size=(B, ls[-1])).astype(np.float32)
+        masks = None
+        if drop:
+            masks = [(rng.random(size=(B, ls[l])) < (pv if l == 0 else ph)).astype(np.uint8) for l in range(L - 1)]
+        o.train_bunch(x, t, masks=masks, gen_masks=False)
+        ws = [None] + [tw[l].clone().requires_grad_(True) for l in range(1, L)]
+        bs = [None] + [tb[l].clone().requires_grad_(True) for l in range(1, L)]
+        y = torch.tensor(x, dtype=torch.float64)
+        for l in range(1, L):
+            if masks is not None:
+                y = y * torch.tensor(1 - masks[l - 1].astype(np.float64))          # non-inverted dropout of the layer INPUT
+            y = y @ ws[l] + bs[l]
+            if l != L - 1:
+                y = torch.relu(y) if act == 0 else torch.sigmoid(y)
+        (((y - torch.tensor(t, dtype=torch.float64)) ** 2).sum() / B).backward()
+        for l in range(1, L):
+            dw[l] = m * dw[l] - c1 * (ws[l].grad / B + wc * tw[l]); tw[l] = tw[l] + dw[l]
+            db[l] = m * db[l] - c1 * (bs[l].grad / B); tb[l] = tb[l] + db[l]
+    for l in range(1, L):
+        assert relerr(o.W[l], tw[l].numpy()) < 2e-6, ("W", l, relerr(o.W[l], tw[l].numpy()))       # fp32 storage of W / delta
+        assert relerr(o.dW[l], dw[l].numpy()) < 2e-5, ("dW", l, relerr(o.dW[l], dw[l].numpy()))
+        assert relerr(o.b[l], tb[l].numpy()) < 2e-5 and relerr(o.db[l], db[l].numpy()) < 2e-5, ("b", l)
+    # CV forward: weights scaled by keep when dropout is configured (BP_GPU.cu:726-746), bias not scaled
+    x = rng.normal(size=(B + 5, ls[0])).astype(np.float32)
+    t = rng.normal(size=(B + 5, ls[-1])).astype(np.float32)
+    y = torch.tensor(x, dtype=torch.float64)
+    for l in range(1, L):
+        keep = (1.0 - (pv if l == 1 else ph)) if drop else 1.0
+        y = y @ (tw[l] * keep) + tb[l]
+        if l != L - 1:
+            y = torch.relu(y) if act == 0 else torch.sigmoid(y)
+    assert relerr(o.forward(x), y.numpy()) < 1e-5
+    sq = float(((y - torch.tensor(t, dtype=torch.float64)) ** 2).sum())
+    assert abs(o.crossvalid(x, t) - sq) < 1e-4 * sq
