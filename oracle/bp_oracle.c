@@ -6,13 +6,16 @@
  * link or import this file.  Allowed users: tests/, __graft_entry__.smoke(), and the
  * `cpu_baseline` leg of bench.py.
  *
- * PARITY UNPINNED: the reference tree holds no golden vectors, known-answer tests or
- * fixtures for this path and the reference itself cannot be
- * built here (BP_GPU.cu/DevFunc.cu need nvcc + cuBLAS + cuRAND; Interface.cc and BPtrain.cc
- * include BP_GPU.h which pulls in <cuda_runtime.h>/<cublas_v2.h>/<curand.h>, none of which
- * exist in this image).  What pins this oracle instead: (1) an independent numpy fp64
- * restatement (oracle/bp_numpy.py), (2) torch autograd of the equivalent loss
- * (tests/test_oracle.py), (3) committed fixtures under tests/golden/ generated from (1).
+ * PARITY UNPINNED for the device path: the reference tree holds no golden vectors, known-answer
+ * tests or fixtures and BP_GPU.cu / DevFunc.cu cannot be built here
+ * (nvcc + cuBLAS + cuRAND are absent; no stand-ins are written).  What pins this oracle instead:
+ * (1) an independent numpy fp64 restatement (oracle/bp_numpy.py) and committed fixtures generated
+ * from it (tests/golden/*.npz), (2) torch float64 autograd -- of one gradient on a small net AND of
+ * multi-step trajectories on 1024-wide layers with momentum, weight cost, both momentum rules, both
+ * activations, injected dropout masks and the keep-scaled CV forward (tests/test_oracle.py).
+ * The reference's HOST code (Interface.cc, BPtrain.cc) is a different matter: it compiles in the
+ * build container against include/BP_GPU.h (oracle/Makefile, target `ref` -> oracle/_ref/), and
+ * pins this repo's reader / planner / weight-file code byte for byte (tests/test_ref_pins.py).
  *
  * What it follows (all paths relative to /root/reference):
  *   BP_GPU.cu:484-673   train_bunch_single : forward, MSE backward, momentum update order
@@ -133,33 +136,76 @@ void oracle_fill_mask(const oracle_cfg *cfg, uint32_t step, uint32_t layer, uint
  * alpha = keep for the CV path (BP_GPU.cu:726-746 scales W by keep, runs the GEMM, scales
  * back), 1 for training.  In the reference keep multiplies W before the products; here it
  * multiplies each weight too so the fp32 rounding matches that order. */
+/* Cache- and register-blocked tiles of the three GEMMs (fp32 mode).  Blocking only changes WHICH output elements are
+ * worked on together: every output element is still one fused-multiply-add chain over its reduction index in ascending
+ * order, starting from the same initial value, so the results are bit-identical to the plain loops they replace
+ * (kept below for fp64 accumulation).  target_clones: AVX-512 where the host has it, the baseline ISA otherwise. */
+#define TILE_F 4
+#define TILE_C 64
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define BP_CLONES __attribute__((target_clones("avx512f", "default")))
+#else
+#define BP_CLONES
+#endif
+
+/* x[f][c0..c0+nc) for nf <= TILE_F frames: bias + sum_k y[f][k] * (W[k][c] * keep) */
+static BP_CLONES void affine_tile(int prev, int cur, const float *y, int nf, const float *W, const float *bias,
+                                  float keep, int c0, int nc, float *x)
+{
+    float acc[TILE_F][TILE_C];
+    for (int i = 0; i < nf; ++i)
+        for (int c = 0; c < nc; ++c) acc[i][c] = bias[c0 + c];
+    if (nf == TILE_F && nc == TILE_C && keep == 1.0f) {            /* the common full tile: fixed trip counts */
+        for (int k = 0; k < prev; ++k) {
+            const float *wr = W + (size_t)k * cur + c0;
+            for (int i = 0; i < TILE_F; ++i) {
+                const float a = y[(size_t)i * prev + k];
+                for (int c = 0; c < TILE_C; ++c) acc[i][c] += a * wr[c];
+            }
+        }
+    } else {
+        for (int k = 0; k < prev; ++k) {
+            const float *wr = W + (size_t)k * cur + c0;
+            for (int i = 0; i < nf; ++i) {
+                const float a = y[(size_t)i * prev + k];
+                if (keep == 1.0f) for (int c = 0; c < nc; ++c) acc[i][c] += a * wr[c];
+                else              for (int c = 0; c < nc; ++c) acc[i][c] += a * (wr[c] * keep);
+            }
+        }
+    }
+    for (int i = 0; i < nf; ++i)
+        for (int c = 0; c < nc; ++c) x[(size_t)i * cur + c0 + c] = acc[i][c];
+}
+
 static void affine(int B, int prev, int cur, const float *y, const float *W, const float *bias,
                    float keep, int acc_double, float *x)
 {
+    if (!acc_double) {
+        const int nfb = (B + TILE_F - 1) / TILE_F, ncb = (cur + TILE_C - 1) / TILE_C;
+        /* column panels outermost: the threads that share a weight panel (prev x 64 floats) run back to back */
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int fb = 0; fb < nfb; ++fb) {
+                const int c0 = cb * TILE_C, f0 = fb * TILE_F;
+                affine_tile(prev, cur, y + (size_t)f0 * prev, B - f0 < TILE_F ? B - f0 : TILE_F, W, bias, keep, c0,
+                            cur - c0 < TILE_C ? cur - c0 : TILE_C, x + (size_t)f0 * cur);
+            }
+        return;
+    }
 #pragma omp parallel for schedule(static)
     for (int f = 0; f < B; ++f) {
         const float *yr = y + (size_t)f * prev;
         float *xr = x + (size_t)f * cur;
-        if (acc_double) {
-            double *acc = (double *)malloc(sizeof(double) * cur);
-            for (int c = 0; c < cur; ++c) acc[c] = bias[c];
-            for (int k = 0; k < prev; ++k) {
-                const double a = yr[k];
-                const float *wr = W + (size_t)k * cur;
-                if (keep == 1.0f) for (int c = 0; c < cur; ++c) acc[c] += a * (double)wr[c];
-                else              for (int c = 0; c < cur; ++c) acc[c] += a * (double)(wr[c] * keep);
-            }
-            for (int c = 0; c < cur; ++c) xr[c] = (float)acc[c];
-            free(acc);
-        } else {
-            for (int c = 0; c < cur; ++c) xr[c] = bias[c];
-            for (int k = 0; k < prev; ++k) {
-                const float a = yr[k];
-                const float *wr = W + (size_t)k * cur;
-                if (keep == 1.0f) for (int c = 0; c < cur; ++c) xr[c] += a * wr[c];
-                else              for (int c = 0; c < cur; ++c) xr[c] += a * (wr[c] * keep);
-            }
+        double *acc = (double *)malloc(sizeof(double) * cur);
+        for (int c = 0; c < cur; ++c) acc[c] = bias[c];
+        for (int k = 0; k < prev; ++k) {
+            const double a = yr[k];
+            const float *wr = W + (size_t)k * cur;
+            if (keep == 1.0f) for (int c = 0; c < cur; ++c) acc[c] += a * (double)wr[c];
+            else              for (int c = 0; c < cur; ++c) acc[c] += a * (double)(wr[c] * keep);
         }
+        for (int c = 0; c < cur; ++c) xr[c] = (float)acc[c];
+        free(acc);
     }
 }
 
@@ -177,64 +223,128 @@ static inline float act_bwd(int activation, float y)
 }
 
 /* dEdY_prev[B][prev] = dEdX[B][cur] . W^T   (DevFunc.h:29-43 SgemmTN, BP_GPU.cu:636) */
+#define TILE_P 8
+#define TILE_FV 32
+/* out[f0..f0+nf)[p0..p0+np) from the transposed error panel dT[c][f]: acc[p][f] += W[p][c] * dT[c][f], c ascending */
+static BP_CLONES void dgrad_tile(int B, int prev, int cur, const float *dT, const float *W, int p0, int np, int f0, int nf, float *out)
+{
+    float acc[TILE_P][TILE_FV];
+    for (int i = 0; i < np; ++i)
+        for (int f = 0; f < nf; ++f) acc[i][f] = 0.0f;
+    if (np == TILE_P && nf == TILE_FV) {
+        for (int c = 0; c < cur; ++c) {
+            const float *dr = dT + (size_t)c * B + f0;
+            for (int i = 0; i < TILE_P; ++i) {
+                const float w = W[(size_t)(p0 + i) * cur + c];
+                for (int f = 0; f < TILE_FV; ++f) acc[i][f] += dr[f] * w;
+            }
+        }
+    } else {
+        for (int c = 0; c < cur; ++c) {
+            const float *dr = dT + (size_t)c * B + f0;
+            for (int i = 0; i < np; ++i) {
+                const float w = W[(size_t)(p0 + i) * cur + c];
+                for (int f = 0; f < nf; ++f) acc[i][f] += dr[f] * w;
+            }
+        }
+    }
+    for (int f = 0; f < nf; ++f)
+        for (int i = 0; i < np; ++i) out[(size_t)(f0 + f) * prev + p0 + i] = acc[i][f];
+}
+
 static void dgrad(int B, int prev, int cur, const float *dedx, const float *W, int acc_double,
                   float *dedy_prev)
 {
+    if (!acc_double) {
+        float *dT = (float *)malloc(sizeof(float) * (size_t)B * cur);        /* [cur][B] */
+#pragma omp parallel for schedule(static)
+        for (int c = 0; c < cur; ++c)
+            for (int f = 0; f < B; ++f) dT[(size_t)c * B + f] = dedx[(size_t)f * cur + c];
+        const int npb = (prev + TILE_P - 1) / TILE_P, nfb = (B + TILE_FV - 1) / TILE_FV;
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int pb = 0; pb < npb; ++pb)
+            for (int fb = 0; fb < nfb; ++fb) {
+                const int p0 = pb * TILE_P, f0 = fb * TILE_FV;
+                dgrad_tile(B, prev, cur, dT, W, p0, prev - p0 < TILE_P ? prev - p0 : TILE_P, f0, B - f0 < TILE_FV ? B - f0 : TILE_FV, dedy_prev);
+            }
+        free(dT);
+        return;
+    }
 #pragma omp parallel for schedule(static)
     for (int f = 0; f < B; ++f) {
         const float *dr = dedx + (size_t)f * cur;
         float *o = dedy_prev + (size_t)f * prev;
         for (int p = 0; p < prev; ++p) {
             const float *wr = W + (size_t)p * cur;
-            if (acc_double) {
-                double s = 0.0;
-                for (int c = 0; c < cur; ++c) s += (double)dr[c] * (double)wr[c];
-                o[p] = (float)s;
-            } else {
-                float s = 0.0f;
-                for (int c = 0; c < cur; ++c) s += dr[c] * wr[c];
-                o[p] = s;
-            }
+            double s = 0.0;
+            for (int c = 0; c < cur; ++c) s += (double)dr[c] * (double)wr[c];
+            o[p] = (float)s;
         }
     }
 }
 
 /* G[prev][cur] = y_prev^T . dEdX  (DevFunc.h:57-67 SgemmNT, BP_GPU.cu:642);
  * gb[cur] = sum_f dEdX[f][:]    (DevFunc.cu:224-242 kernAccSumrow with alpha=0,beta=1). */
-static void wgrad(int B, int prev, int cur, const float *y_prev, const float *dedx,
-                  int acc_double, float *G, float *gb)
+static BP_CLONES void wgrad_tile(int B, int prev, int cur, const float *y_prev, const float *dedx, int p0, int np, int c0, int nc, float *G)
 {
-#pragma omp parallel for schedule(static)
-    for (int p = 0; p < prev; ++p) {
-        float *gr = G + (size_t)p * cur;
-        if (acc_double) {
-            double *acc = (double *)calloc(cur, sizeof(double));
-            for (int f = 0; f < B; ++f) {
-                const double a = y_prev[(size_t)f * prev + p];
-                const float *dr = dedx + (size_t)f * cur;
-                for (int c = 0; c < cur; ++c) acc[c] += a * (double)dr[c];
+    float acc[TILE_F][TILE_C];
+    for (int i = 0; i < np; ++i)
+        for (int c = 0; c < nc; ++c) acc[i][c] = 0.0f;
+    if (np == TILE_F && nc == TILE_C) {
+        for (int f = 0; f < B; ++f) {
+            const float *dr = dedx + (size_t)f * cur + c0, *yr = y_prev + (size_t)f * prev + p0;
+            for (int i = 0; i < TILE_F; ++i) {
+                const float a = yr[i];
+                for (int c = 0; c < TILE_C; ++c) acc[i][c] += a * dr[c];
             }
-            for (int c = 0; c < cur; ++c) gr[c] = (float)acc[c];
-            free(acc);
-        } else {
-            for (int c = 0; c < cur; ++c) gr[c] = 0.0f;
-            for (int f = 0; f < B; ++f) {
-                const float a = y_prev[(size_t)f * prev + p];
-                const float *dr = dedx + (size_t)f * cur;
-                for (int c = 0; c < cur; ++c) gr[c] += a * dr[c];
+        }
+    } else {
+        for (int f = 0; f < B; ++f) {
+            const float *dr = dedx + (size_t)f * cur + c0, *yr = y_prev + (size_t)f * prev + p0;
+            for (int i = 0; i < np; ++i) {
+                const float a = yr[i];
+                for (int c = 0; c < nc; ++c) acc[i][c] += a * dr[c];
             }
         }
     }
-    for (int c = 0; c < cur; ++c) {
-        if (acc_double) {
-            double s = 0.0;
-            for (int f = 0; f < B; ++f) s += dedx[(size_t)f * cur + c];
-            gb[c] = (float)s;
-        } else {
-            float s = 0.0f;                       /* kernAccSumrow: sequential over frames */
-            for (int f = 0; f < B; ++f) s += dedx[(size_t)f * cur + c];
-            gb[c] = s;
+    for (int i = 0; i < np; ++i)
+        for (int c = 0; c < nc; ++c) G[(size_t)(p0 + i) * cur + c0 + c] = acc[i][c];
+}
+
+static void wgrad(int B, int prev, int cur, const float *y_prev, const float *dedx,
+                  int acc_double, float *G, float *gb)
+{
+    if (!acc_double) {
+        const int npb = (prev + TILE_F - 1) / TILE_F, ncb = (cur + TILE_C - 1) / TILE_C;
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int cb = 0; cb < ncb; ++cb)
+            for (int pb = 0; pb < npb; ++pb) {
+                const int p0 = pb * TILE_F, c0 = cb * TILE_C;
+                wgrad_tile(B, prev, cur, y_prev, dedx, p0, prev - p0 < TILE_F ? prev - p0 : TILE_F, c0, cur - c0 < TILE_C ? cur - c0 : TILE_C, G);
+            }
+        for (int c = 0; c < cur; ++c) gb[c] = 0.0f;
+        for (int f = 0; f < B; ++f) {                 /* kernAccSumrow: sequential over frames for every column */
+            const float *dr = dedx + (size_t)f * cur;
+            for (int c = 0; c < cur; ++c) gb[c] += dr[c];
         }
+        return;
+    }
+#pragma omp parallel for schedule(static)
+    for (int p = 0; p < prev; ++p) {
+        float *gr = G + (size_t)p * cur;
+        double *acc = (double *)calloc(cur, sizeof(double));
+        for (int f = 0; f < B; ++f) {
+            const double a = y_prev[(size_t)f * prev + p];
+            const float *dr = dedx + (size_t)f * cur;
+            for (int c = 0; c < cur; ++c) acc[c] += a * (double)dr[c];
+        }
+        for (int c = 0; c < cur; ++c) gr[c] = (float)acc[c];
+        free(acc);
+    }
+    for (int c = 0; c < cur; ++c) {
+        double s = 0.0;
+        for (int f = 0; f < B; ++f) s += dedx[(size_t)f * cur + c];
+        gb[c] = (float)s;
     }
 }
 
