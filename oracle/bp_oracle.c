@@ -10,7 +10,7 @@
  * tests or fixtures and BP_GPU.cu / DevFunc.cu cannot be built here
  * (nvcc + cuBLAS + cuRAND are absent; no stand-ins are written).  What pins this oracle instead:
  * (1) an independent numpy fp64 restatement (oracle/bp_numpy.py) and committed fixtures generated
- * from it (tests/golden/*.npz), (2) torch float64 autograd -- of one gradient on a small net AND of
+ * from it (the .npz files under tests/golden), (2) torch float64 autograd -- of one gradient on a small net AND of
  * multi-step trajectories on 1024-wide layers with momentum, weight cost, both momentum rules, both
  * activations, injected dropout masks and the keep-scaled CV forward (tests/test_oracle.py).
  * The reference's HOST code (Interface.cc, BPtrain.cc) is a different matter: it compiles in the
