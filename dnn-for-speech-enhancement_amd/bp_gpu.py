@@ -71,7 +71,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("BP_HIP_LIB", LIB_PATH)   # (BP_HIP_LIB: development builds of the same ABI)
     if not os.path.exists(p):
         raise BPError("HIP library %s not found: build it with `python __graft_entry__.py` "
                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)

@@ -20,6 +20,7 @@
 #include "bp_kernels.h"
 #include "bp_bf16.h"
 #include "bp_dp.h"
+#include "bp_wgrad_dma.h"
 
 #include <atomic>
 #include <chrono>
@@ -382,8 +383,8 @@ using KDgradNarrow = GemmKernel<32, 32, 64, 1, 1, true, true, EPI_DGRAD>;
 // lets the prologue / W,delta round trip of one workgroup hide behind the MFMA phase of the others
 // (128x64 tiles move 25 % less through L2 but fit only 2 per CU: 0.242 vs 0.230 ms per C2 step).
 template <int EPI> using KWgrad = GemmKernel<64, 64, 32, 2, 2, false, false, EPI>;
-// bunch of 256 frames = 8 k-tiles: fully unrolled k-loop with the W/delta fetch spread over it
-using KWgrad256 = GemmKernel<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE, 1, 8>;
+// bunch of 256 frames (the benchmark configuration): LDS-DMA staged, fully unrolled kernel of bp_wgrad_dma.h; the
+// register-staged unrolled form it replaced was GemmKernel<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE, 1, 8> (84.7 vs 80.4 us)
 // data-parallel gradient store (no W/delta to carry): 128x64x16 tiles are 136 VGPRs and measured faster there
 using KWgradStore = GemmKernel<128, 64, 16, 2, 2, false, false, EPI_WGRAD_STORE>;
 
@@ -442,16 +443,35 @@ static hipError_t run_multi(hipStream_t st, Prepared *ps, int n)
     return hipGetLastError();
 }
 
+// The same for a plain __global__ kernel taking MultiArgs with 64x64 tiles (bp_wgrad_dma.h).
+template <void (*KERNEL)(const MultiArgs)>
+static hipError_t run_multi_k(hipStream_t st, Prepared *ps, int n)
+{
+    MultiArgs a; memset(&a, 0, sizeof(a));
+    int t = 0;
+    for (int i = 0; i < n; ++i) {
+        ps[i].g.tiles_m = (ps[i].M + 63) / 64; ps[i].g.tiles_n = (ps[i].N + 63) / 64;
+        a.g[i] = ps[i].g; a.e[i] = ps[i].e; a.first_tile[i] = t;
+        t += (ps[i].g.tiles_m * ps[i].g.tiles_n + 7) & ~7;      // (problem-relative block index keeps the XCD bits, see run_multi)
+    }
+    a.first_tile[n] = t; a.n = n;
+    hipLaunchKernelGGL(KERNEL, dim3(t), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 // The wgrad problems ps[0..n) (all fused or all store): grouped launches of up to 4 problems, or one each.
 static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
 {
     for (int i = 0; i < n;) {
         const int m = grouped ? (n - i < 4 ? n - i : 4) : 1;
         static const bool no_static = getenv("BP_WGRAD_DYNAMIC") != nullptr;    // development A/B switch
-        bool k256 = ps[i].fused && !no_static;
-        for (int j = 0; j < m; ++j) k256 = k256 && ps[i + j].g.K == 256;
+        // bunches of 128 / 256 / 512 frames (the shipped .pl uses 128, BASELINE.json 256 and 512): LDS-DMA kernel, unrolled
+        int kk = ps[i].fused && !no_static ? ps[i].g.K : 0;
+        for (int j = 0; j < m; ++j) if (ps[i + j].g.K != kk) kk = 0;
         hipError_t er;
-        if (k256) er = run_multi<KWgrad256, 64, 64>(st, ps + i, m);
+        if (kk == 256) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 256>>(st, ps + i, m);
+        else if (kk == 128) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 128>>(st, ps + i, m);
+        else if (kk == 512) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 512>>(st, ps + i, m);
         else if (ps[i].fused) er = run_multi<KWgrad<EPI_WGRAD_UPDATE>, 64, 64>(st, ps + i, m);
         else er = run_multi<KWgradStore, 128, 64>(st, ps + i, m);
         if (er != hipSuccess) return er;

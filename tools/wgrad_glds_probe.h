@@ -183,3 +183,5 @@ __global__ __launch_bounds__(256, WgradGlds<TM>::MIN_WG) void bp_wgrad_glds_mult
     while (p + 1 < a.n && b >= a.first_tile[p + 1]) ++p;
     WgradGlds<TM>::run(a.g[p], a.e[p], b - a.first_tile[p], a.first_tile[p + 1] - a.first_tile[p], smem);
 }
+
+// (the adopted static-K form of this design is the product kernel: dnn-for-speech-enhancement_amd/csrc/bp_wgrad_dma.h)
