@@ -41,6 +41,9 @@
  * the same counter-based Philox4x32-10 stream the HIP kernels use (see bp_philox_drop).
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -80,6 +83,25 @@ static float *bf16_copy(const float *src, size_t n)
     float *d = (float *)malloc(sizeof(float) * (n ? n : 1));
     for (size_t i = 0; i < n; ++i) d[i] = bf16_round(src[i]);
     return d;
+}
+
+/* Threads the OpenMP loops use (the timing leg of bench.py picks the count that is fastest on the host: on a box whose
+ * cgroup grants fewer cores than it shows, 256 spinning threads are 70x slower than 16). */
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 /* ------------------------------------------------------------------ Philox4x32-10 */

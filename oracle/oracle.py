@@ -198,5 +198,13 @@ class Oracle:
         return n
 
 
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
 def drop_threshold(p):
     return int(lib().bp_drop_threshold(p))
