@@ -53,12 +53,16 @@ static constexpr int BF_NPF = 3;                                     // k-tiles 
 // BM = 64: 256 threads, waves 2 x 2.  BM = 32: 128 threads, waves 1 x 2 -- twice the workgroups for the M = bunch GEMMs.
 // The MFMA work per k-tile is tiny (4 x v_mfma_f32_32x32x16_bf16 per wave), so the loop is bound by the latency of the
 // tile loads: BF_NPF tiles are kept in flight in registers, two LDS stages, one barrier per k-tile.
+// BM = 128: 256 threads, waves 2 x 2, each wave TWO 32x32 blocks along m (64 x 32): a third less operand traffic per
+// FLOP than 64 x 64 and every B fragment feeds two MFMAs -- used when 128-row tiles still give every CU a workgroup
+// (the 4096-wide layers of configs[4]: these GEMMs are bound by operand delivery into the CUs, not by the bf16 MFMA rate).
 template <int EPI, int BM>
-__global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
+__global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
 {
-    constexpr int NTHR = BM * 4, ROWS = BM + BF_BN, NCHK = ROWS * 8 / NTHR;     // 16-byte chunks per thread and tile
+    constexpr int NTHR = BM == 32 ? 128 : 256, ROWS = BM + BF_BN, NCHK = ROWS * 8 / NTHR;     // 16-byte chunks per thread and tile
+    constexpr int TMB = BM == 128 ? 2 : 1;                                                      // 32x32 blocks per wave along m
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ROWS * BF_LDS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = (BM == 64) ? wave >> 1 : 0, wn = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = (BM >= 64) ? wave >> 1 : 0, wn = wave & 1;
     // XCD-aware tile map (block b runs on XCD b % 8): the workgroups that share a B panel (same tile_n, all tile_m)
     // sit on one XCD, so the panel is fetched into that XCD's L2 once instead of eight times
     int tile_m, tile_n;
@@ -79,31 +83,37 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
     }
     // ---- epilogue mapping: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block
     const int n = n0 + wn * 32 + (lane & 31);
-    const int rbase = m0 + wm * 32 + 4 * (lane >> 5);   // (wm = 0 for BM = 32)
+    const int rbase = m0 + wm * 32 * TMB + 4 * (lane >> 5);   // (wm = 0 for BM = 32); block i of the wave: + 32*i
     const bool live = n < e.n_true;
     // Everything the epilogue READS (targets | y_{l-1} | W, delta) is fetched here, BEFORE the k-loop, in one burst: its
     // latency hides under the loop (wgrad has only bunch/64 k-tiles, so a workgroup is otherwise one round trip for
     // the tiles plus one for W/delta), and no load has to wait behind the epilogue's stores, which go through
     // pointers the compiler must assume may alias the inputs.
-    float in0[16], in1[16];
+    float in0[TMB][16], in1[TMB][16];
     float bn = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { in0[r] = 0.0f; in1[r] = 0.0f; }
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { in0[b][r] = 0.0f; in1[b][r] = 0.0f; }
     if (n < e.n_limit) {
         if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_FWD_OUT) bn = e.bias[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = rbase + (r & 3) + 8 * (r >> 2);
-            if (m < e.m_limit) {
-                if constexpr (EPI == BEPI_FWD_OUT) { if (e.C && live) in0[r] = e.targ[(size_t)m * e.ldt + n]; }
-                if constexpr (EPI == BEPI_DGRAD) in0[r] = bf2f(e.yprev[(size_t)m * e.ldy + n]);
-                if constexpr (EPI == BEPI_WGRAD_UPDATE) { in0[r] = e.W[(size_t)m * e.ldw + n]; in1[r] = e.D[(size_t)m * e.ldw + n]; }
-            }
-        }
-    }
-    f32x16 acc;
+        for (int b = 0; b < TMB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) {
+                const int m = rbase + 32 * b + (r & 3) + 8 * (r >> 2);
+                if (m < e.m_limit) {
+                    if constexpr (EPI == BEPI_FWD_OUT) { if (e.C && live) in0[b][r] = e.targ[(size_t)m * e.ldt + n]; }
+                    if constexpr (EPI == BEPI_DGRAD) in0[b][r] = bf2f(e.yprev[(size_t)m * e.ldy + n]);
+                    if constexpr (EPI == BEPI_WGRAD_UPDATE) { in0[b][r] = e.W[(size_t)m * e.ldw + n]; in1[b][r] = e.D[(size_t)m * e.ldw + n]; }
+                }
+            }
+    }
+    f32x16 accs[TMB];
+#pragma unroll
+    for (int b = 0; b < TMB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[b][r] = 0.0f;
     const int nt = g.K / BF_BK;
     // three register images of a tile, always addressed by name (a runtime-indexed array would live in scratch)
     struct Img { uint4 v[NCHK]; };
@@ -118,22 +128,22 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
         _Pragma("unroll") for (int i = 0; i < NCHK; ++i) { const uint4 v_ = R.v[i];                     \
             *reinterpret_cast<uint4 *>(smem + (st) * ROWS * BF_LDS + dst[i]) = v_; }                    \
     } while (0)
-    const int arow = wm * 32 + (lane & 31), brow = BM + wn * 32 + (lane & 31), kh = (lane >> 5) * 8;
+    const int arow = wm * 32 * TMB + (lane & 31), brow = BM + wn * 32 + (lane & 31), kh = (lane >> 5) * 8;
 // multiply tile t (LDS stage t&1); RN holds tile t+1: move it to the other stage and refill RN with tile t+1+NPF
 #define BF_ITER(t, RN)                                                                                  \
     do {                                                                                                \
         const bf16_t *base_ = smem + ((t) & 1) * ROWS * BF_LDS;                                         \
         const bf16_t *ap_ = base_ + arow * BF_LDS + kh, *bp_ = base_ + brow * BF_LDS + kh;              \
-        const bf16x8_t a0_ = *reinterpret_cast<const bf16x8_t *>(ap_), a1_ = *reinterpret_cast<const bf16x8_t *>(ap_ + 16), \
-                       a2_ = *reinterpret_cast<const bf16x8_t *>(ap_ + 32), a3_ = *reinterpret_cast<const bf16x8_t *>(ap_ + 48); \
-        const bf16x8_t b0_ = *reinterpret_cast<const bf16x8_t *>(bp_), b1_ = *reinterpret_cast<const bf16x8_t *>(bp_ + 16), \
-                       b2_ = *reinterpret_cast<const bf16x8_t *>(bp_ + 32), b3_ = *reinterpret_cast<const bf16x8_t *>(bp_ + 48); \
+        bf16x8_t a_[TMB][4], b_[4];                                                                     \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                              \
+            b_[q_] = *reinterpret_cast<const bf16x8_t *>(bp_ + 16 * q_);                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < TMB; ++i_) a_[i_][q_] = *reinterpret_cast<const bf16x8_t *>(ap_ + i_ * 32 * BF_LDS + 16 * q_); \
+        }                                                                                               \
         BF_STORE(RN, ((t) + 1) & 1);               /* (past the last tile: a clamped duplicate nobody reads) */ \
         BF_LOAD(RN, (t) + 1 + BF_NPF);                                                                  \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc, 0, 0, 0);                          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc, 0, 0, 0);                          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b2_, acc, 0, 0, 0);                          \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b3_, acc, 0, 0, 0);                          \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                \
+            _Pragma("unroll") for (int i_ = 0; i_ < TMB; ++i_)                                          \
+                accs[i_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i_][q_], b_[q_], accs[i_], 0, 0, 0); \
         __syncthreads();                                                                                \
     } while (0)
     // tile t waits in image r(t % 3) until it is moved to LDS stage t & 1
@@ -151,8 +161,11 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
     // ---- epilogue
     if (n >= e.n_limit) return;
 #pragma unroll
+    for (int blk = 0; blk < TMB; ++blk) {
+    const f32x16 &acc = accs[blk];
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int mq = rbase + 8 * q;                 // 4 consecutive rows mq..mq+3 (mq % 4 == 0)
+        const int mq = rbase + 32 * blk + 8 * q;      // 4 consecutive rows mq..mq+3 (mq % 4 == 0)
         float v[4];
         if constexpr (EPI == BEPI_FWD_HIDDEN) {
             uint32_t w[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -172,7 +185,7 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
                 if (m < e.m_limit) {
                     const float o = live ? e.alpha * acc[4 * q + j] + bn : 0.0f;
                     if (e.out) e.out[(size_t)m * e.ldo + n] = o;
-                    if (e.C && live) d = e.scale * (o - in0[4 * q + j]);                     // kernSubClean
+                    if (e.C && live) d = e.scale * (o - in0[blk][4 * q + j]);                     // kernSubClean
                 }
                 v[j] = d;
             }
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
         } else if constexpr (EPI == BEPI_DGRAD) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                v[j] = (mq + j < e.m_limit && live) ? act_bwd(e.act, in0[4 * q + j]) * acc[4 * q + j] : 0.0f;
+                v[j] = (mq + j < e.m_limit && live) ? act_bwd(e.act, in0[blk][4 * q + j]) * acc[4 * q + j] : 0.0f;
         } else {                                      // wgrad: rows = units of layer l-1, cols = units of layer l
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -188,8 +201,8 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
                 if (m >= e.m_limit) { v[j] = 0.0f; continue; }
                 const size_t i = (size_t)m * e.ldw + n;
                 if constexpr (EPI == BEPI_WGRAD_UPDATE) {
-                    const float w = in0[4 * q + j];
-                    const float d = e.mom * in1[4 * q + j] - e.c1 * (acc[4 * q + j] / e.ndiv + e.wc * w);   // kernUpdatedelta
+                    const float w = in0[blk][4 * q + j];
+                    const float d = e.mom * in1[blk][4 * q + j] - e.c1 * (acc[4 * q + j] / e.ndiv + e.wc * w);   // kernUpdatedelta
                     e.D[i] = d;
                     v[j] = d + 1.0f * w;                                                                    // kernAccSum
                     e.W[i] = v[j];
@@ -209,6 +222,7 @@ __global__ __launch_bounds__(BM * 4, 2) void bp_gemm_bf16(const BfGemmArgs g, co
             if (mq + j < e.m_limit) e.C[(size_t)(mq + j) * e.ldc + n] = hb[j];
         const uint2 pk = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
         *reinterpret_cast<uint2 *>(e.CT + (size_t)n * e.ldct + mq) = pk;
+    }
     }
 }
 

@@ -532,7 +532,11 @@ template <int EPI>
 static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int M, int N)
 {
     g.tiles_n = N / 64;
-    if ((M / 64) * g.tiles_n >= 512) {
+    static const bool no128 = getenv("BP_BF16_NO128") != nullptr;                 // development A/B switch
+    if (!no128 && M % 128 == 0 && (M / 128) * g.tiles_n >= 256) {                 // 128-row tiles still fill the chip
+        g.tiles_m = M / 128;
+        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
+    } else if ((M / 64) * g.tiles_n >= 512) {
         g.tiles_m = M / 64;
         hipLaunchKernelGGL((bp_gemm_bf16<EPI, 64>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
     } else {

@@ -12,6 +12,7 @@
 #include <vector>
 #include "../dnn-for-speech-enhancement_amd/csrc/bp_kernels.h"
 #include "wgrad_glds_probe.h"
+#include "fwd_glds_probe.h"
 
 template <int NACC>
 __global__ __launch_bounds__(256) void mfma_peak(float *out, int iters)
@@ -107,6 +108,11 @@ int main(int argc, char **argv)
     vs.push_back({"wgrad glds 128x64x16 3-stage", [&](hipStream_t s) { MultiArgs a; memset(&a, 0, sizeof(a)); wg_args(a.g[0], a.e[0]);
         a.g[0].tiles_m = H / 128; a.g[0].tiles_n = H / 64; a.first_tile[0] = 0; a.first_tile[1] = a.g[0].tiles_m * a.g[0].tiles_n; a.n = 1;
         hipLaunchKernelGGL(bp_wgrad_glds_multi<2>, dim3(a.first_tile[1]), dim3(256), 0, s, a); }, 2.0 * H * H * (double)KW});
+    // LDS-DMA staged M = 256 GEMMs (fwd_glds_probe.h)
+    vs.push_back({"fwd  glds 32x64x64 4-stage", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
+        hipLaunchKernelGGL((bp_gemm_dma<false, EPI_FWD_HIDDEN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
+    vs.push_back({"dgrad glds 32x64x64 4-stage", [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
+        hipLaunchKernelGGL((bp_gemm_dma<true, EPI_DGRAD>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
     // short-kernel MFMA shapes: G workgroups x 4 waves x N MFMAs per wave, NACC chains (what a 64x64x256 wgrad tile issues: 128 per wave)
 #define SHAPE(G, N, NACC) vs.push_back({"mfma shape G" #G " n" #N " chains" #NACC, [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<NACC>, dim3(G), dim3(256), 0, s, Yo, N / NACC); }, (double)G * 4 * N * 4096.0})
     SHAPE(1024, 128, 2); SHAPE(768, 128, 2); SHAPE(256, 128, 2); SHAPE(1024, 128, 4); SHAPE(1024, 128, 1); SHAPE(256, 512, 2); SHAPE(3648, 128, 2); SHAPE(2048, 128, 2);
@@ -134,6 +140,26 @@ int main(int argc, char **argv)
         for (int i = 0; i < H; ++i) { mb = std::max(mb, (double)fabsf(b1[i] - b2[i])); sb = std::max(sb, (double)fabsf(b1[i])); }
         printf("CHECK glds vs static8: max|dW| %.3e (update size %.3e)  max|dDelta| %.3e (|delta| %.3e)  max|dbias| %.3e (|bias| %.3e)\n", mw, sw, md, sd, mb, sb);
         CK(hipMemcpy(W, w0.data(), nW * 4, hipMemcpyHostToDevice)); CK(hipMemset(D, 0, nW * 4));
+    }
+    if (getenv("PROBE_CHECK2")) {
+        const size_t nY = (size_t)B * LD;
+        std::vector<float> r1(nY), r2(nY);
+        for (int kind = 0; kind < 2; ++kind) {
+            for (int which = 0; which < 2; ++which) {
+                CK(hipMemset(Yo, 0, nY * 4));
+                GemmArgs g; EpiArgs e;
+                if (kind == 0) { fwd_args(g, e); e.drop_thresh = 0; } else dg_args(g, e);
+                if (which == 0) { if (kind == 0) go<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>(st, g, e, B, H, 0); else go<32, 64, 64, 1, 2, true, true, EPI_DGRAD, 1>(st, g, e, B, H, 0); }
+                else { g.tiles_m = B / 32; g.tiles_n = H / 64;
+                       if (kind == 0) hipLaunchKernelGGL((bp_gemm_dma<false, EPI_FWD_HIDDEN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, st, g, e);
+                       else hipLaunchKernelGGL((bp_gemm_dma<true, EPI_DGRAD>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, st, g, e); }
+                CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+                CK(hipMemcpy(which ? r2.data() : r1.data(), Yo, nY * 4, hipMemcpyDeviceToHost));
+            }
+            double md = 0, mx = 0; size_t nz = 0;
+            for (size_t i = 0; i < nY; ++i) { md = std::max(md, (double)fabsf(r1[i] - r2[i])); mx = std::max(mx, (double)fabsf(r1[i])); nz += r2[i] != 0.f; }
+            printf("CHECK2 %s glds vs product: max|diff| %.3e, max|ref| %.3e, nonzero outputs %zu of %zu\n", kind ? "dgrad" : "fwd", md, mx, nz, nY);
+        }
     }
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int lds[] = {2048, 2112, 2176, 2304};
