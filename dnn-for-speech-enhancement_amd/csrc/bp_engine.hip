@@ -466,12 +466,15 @@ static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
         const int m = grouped ? (n - i < 4 ? n - i : 4) : 1;
         static const bool no_static = getenv("BP_WGRAD_DYNAMIC") != nullptr;    // development A/B switch
         // bunches of 128 / 256 / 512 frames (the shipped .pl uses 128, BASELINE.json 256 and 512): LDS-DMA kernel, unrolled
-        int kk = ps[i].fused && !no_static ? ps[i].g.K : 0;
+        int kk = !no_static ? ps[i].g.K : 0;
         for (int j = 0; j < m; ++j) if (ps[i + j].g.K != kk) kk = 0;
         hipError_t er;
-        if (kk == 256) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 256>>(st, ps + i, m);
-        else if (kk == 128) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 128>>(st, ps + i, m);
-        else if (kk == 512) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 512>>(st, ps + i, m);
+        if (kk == 256 && ps[i].fused) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 256>>(st, ps + i, m);
+        else if (kk == 128 && ps[i].fused) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 128>>(st, ps + i, m);
+        else if (kk == 512 && ps[i].fused) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 512>>(st, ps + i, m);
+        else if (kk == 256) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 256, true>>(st, ps + i, m);       // data-parallel gradient store
+        else if (kk == 128) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 128, true>>(st, ps + i, m);
+        else if (kk == 512) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 512, true>>(st, ps + i, m);
         else if (ps[i].fused) er = run_multi<KWgrad<EPI_WGRAD_UPDATE>, 64, 64>(st, ps + i, m);
         else er = run_multi<KWgradStore, 128, 64>(st, ps + i, m);
         if (er != hipSuccess) return er;
@@ -1599,8 +1602,14 @@ __global__ __launch_bounds__(256) void bp_peak_mfma_f32(float *sink, int iters, 
 }
 __global__ __launch_bounds__(256) void bp_peak_copy(float4 *dst, const float4 *src, size_t n4)
 {
+    // 4 independent 16-byte loads in flight per lane, then 4 stores; consecutive lanes touch consecutive 16-byte words
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 extern "C" int bp_measure_peaks(bp_handle *h, float *mfma_f32_tflops, float *hbm_copy_gbs)
 {
@@ -1630,7 +1639,7 @@ extern "C" int bp_measure_peaks(bp_handle *h, float *mfma_f32_tflops, float *hbm
     best = 0.f;
     for (int rep = 0; rep < 4; ++rep) {
         HIPCHK(hipEventRecord(a, h->stream));
-        hipLaunchKernelGGL(bp_peak_copy, dim3(256 * 16), dim3(256), 0, h->stream, dst, src, bytes / 16);
+        hipLaunchKernelGGL(bp_peak_copy, dim3(256 * (rep < 2 ? 8 : 32)), dim3(256), 0, h->stream, dst, src, bytes / 16);   // two grid sizes, best reported
         HIPCHK(hipEventRecord(b, h->stream));
         HIPCHK(hipEventSynchronize(b));
         HIPCHK(hipEventElapsedTime(&ms, a, b));

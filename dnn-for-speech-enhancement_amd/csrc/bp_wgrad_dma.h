@@ -22,8 +22,12 @@
 // template <BK, ST, MINWG, K>: K = frames of the bunch (static).  Prefetch distance D = ST-1 tiles.
 template <int N> struct VmWait { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory"); } };
 
-template <int BKX, int STX, int MINWG, int KTOT>
+template <int BKX, int STX, int MINWG, int KTOT, bool STORE = false>
 struct WgradDma {
+    // STORE: data-parallel form -- the gradient tile and the bias gradient go to the flat gradient buffer (e.C / e.bias_g),
+    // no W / delta traffic; otherwise the fused momentum update
+    static constexpr int EPI = STORE ? EPI_WGRAD_STORE : EPI_WGRAD_UPDATE;
+    static constexpr int NWD = STORE ? 0 : 32;                    // plain loads of the W / delta tile per lane
     static constexpr int BM = 64, BN = 64, BK = BKX, ST = STX, NT = KTOT / BKX, D = STX - 1;
     static constexpr int A_STAGE = BK * BM, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;
     static constexpr int SMEM = ST * STAGE;
@@ -70,10 +74,10 @@ struct WgradDma {
             // in flight at this point: tiles T .. min(T+D, NT)-1, plus the 32 W/delta loads once the last tile has been issued
             constexpr int tiles_after = (T + D < NT ? D : NT - T) - 1;
             constexpr bool wd_out = T + D > NT;                       // W/delta were issued in an earlier iteration (right after tile NT-1)
-            VmWait<tiles_after * NDMA + (wd_out ? 32 : 0)>::go();
+            VmWait<tiles_after * NDMA + (wd_out ? NWD : 0)>::go();
             __builtin_amdgcn_s_barrier();
             if constexpr (T + D < NT) issue_tile(g, m0, n0, (T + D) * BK, smem, (T + D) % ST, wave, lane);
-            if constexpr (T + D == NT) epilogue_fetch<EPI_WGRAD_UPDATE, 0, 16>(e, mb, nb, lane, pre);   // behind the last tile (issued at T-1)
+            if constexpr (T + D == NT && !STORE) epilogue_fetch<EPI_WGRAD_UPDATE, 0, 16>(e, mb, nb, lane, pre);   // behind the last tile (issued at T-1)
             if (do_bias) {
                 constexpr int RPT = BK / 4;
                 const float *bs = smem + (T % ST) * STAGE + A_STAGE + (tid >> 6) * RPT * BN + (tid & 63);
@@ -113,21 +117,25 @@ struct WgradDma {
                 if (tid < BN && n0 + tid < e.n_limit) {
                     const float s = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
                     const int n = n0 + tid;
-                    const float d = e.mom * e.bias_d[n] - e.c1 * (s / e.ndiv + 0.0f * e.bias_w[n]);
-                    e.bias_d[n] = d;
-                    e.bias_w[n] = d + 1.0f * e.bias_w[n];
+                    if constexpr (STORE) {
+                        e.bias_g[n] = s;
+                    } else {
+                        const float d = e.mom * e.bias_d[n] - e.c1 * (s / e.ndiv + 0.0f * e.bias_w[n]);
+                        e.bias_d[n] = d;
+                        e.bias_w[n] = d + 1.0f * e.bias_w[n];
+                    }
                 }
                 __syncthreads();
             }
-            epilogue_block<EPI_WGRAD_UPDATE, 0, 16>(e, mb, nb, acc[0], lane, pre);
+            epilogue_block<EPI, 0, 16>(e, mb, nb, acc[0], lane, pre);
         }
     }
 };
 
-template <int BKX, int STX, int MINWG, int KTOT>
+template <int BKX, int STX, int MINWG, int KTOT, bool STORE = false>
 __global__ __launch_bounds__(256, MINWG) void bp_wgrad_dma(const MultiArgs a)
 {
-    using K = WgradDma<BKX, STX, MINWG, KTOT>;
+    using K = WgradDma<BKX, STX, MINWG, KTOT, STORE>;
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     const int b = blockIdx.x;
     int p = 0;
