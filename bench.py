@@ -286,7 +286,7 @@ def main():
         try:
             import csv
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv"))):
-                if row["Name"].startswith("void bp_wgrad_dma<16, 4, 4, 256>"):
+                if row["Name"].startswith("void bp_wgrad_dma<16, 4, 4, 256") and "true" not in row["Name"]:     # (the fused-update form)
                     rk_ms = float(row["AverageNs"]) * 1e-6
         except Exception:
             rk_ms = None
