@@ -487,3 +487,41 @@ def test_bf16_config5_shape_one_step(pkg, oracle_mod):
         assert relerr_rms(dbb[l], od.db[l]) < TOL_BF16 + 1.5 * spread_b, ("db", l, relerr_rms(dbb[l], od.db[l]), spread_b)
         assert relerr(w[l], o.W[l]) < TOL_BF16, ("W", l)
     g.close()
+
+
+def test_public_members_are_live_between_chunks(pkg, oracle_mod):
+    """The reference reads lrate / momentum / weightcost / dropout settings from its public members on every bunch
+    (BP_GPU.cu:488-500): assigning them between train() calls must take effect (bp_set_hyper)."""
+    ls, B = [24, 32, 8], 16
+    W, b = N.glorot_net(ls, seed=3, beta=1.0)
+    rng = np.random.default_rng(4)
+    x = rng.normal(size=(4 * B, ls[0])).astype(np.float32)
+    t = rng.normal(size=(4 * B, ls[-1])).astype(np.float32)
+    g = _mk(pkg, ls, B, W, b, lr=1.0, m=0.5, wc=0.0)
+    o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b)
+    g.train(2 * B, x[:2 * B], t[:2 * B]); o.train(x[:2 * B], t[:2 * B])
+    g.lrate, g.momentum, g.weightcost = 0.25, 0.9, 0.01            # like `TrainObj->lrate = ...` in a C++ caller
+    o.cfg.lrate, o.cfg.momentum, o.cfg.weightcost = 0.25, 0.9, 0.01
+    g.train(2 * B, x[2 * B:], t[2 * B:]); o.train(x[2 * B:], t[2 * B:])
+    w, bb = g.get_weights()
+    for l in (1, 2):
+        assert relerr(w[l], o.W[l]) < TOL and relerr(bb[l], o.b[l]) < TOL
+    w0 = [a.copy() for a in w[1:]]
+    g.lrate, g.momentum = 0.0, 0.0                                   # no learning: weights must not move
+    g.train(2 * B, x[:2 * B], t[:2 * B])
+    w1, _ = g.get_weights()
+    assert all(np.array_equal(a, c) for a, c in zip(w0, w1[1:]))
+    g.close()
+
+
+def test_visible_mask_over_a_chunk_larger_than_the_old_grid_limit(pkg):
+    """A dropout chunk of more than 65535*4 frames used to exceed the y-grid limit of the visible-mask kernel."""
+    ls, B, n = [8, 16, 4], 64, 65536 * 4 + 2 * 64
+    W, b = N.glorot_net(ls, seed=1, beta=1.0)
+    g = pkg.BP_GPU(1, 3, ls, B, 0.01, 0.5, 0.0, W, b, dropoutflag=1, visible_omit=0.2, hid_omit=0.2, seed=5, max_chunk_frames=n)
+    g.fill_chunk_synthetic(n, 3)
+    g.train_resident(0, n)
+    g.sync()
+    w, _ = g.get_weights()
+    assert all(np.isfinite(a).all() for a in w[1:]) and not np.array_equal(w[1], W[1])
+    g.close()
