@@ -156,6 +156,52 @@ def c5_line(dnnse_amd, dev, steps=40):
             "frac_of_bf16_mfma_peak": flops_per_frame(C5_LAYERS) * C5_BUNCH / dt / 2.5e15}
 
 
+def c1_end_to_end_line():
+    """BASELINE.json configs[0] (the plumbing configuration): 1x512 Sigmoid net on 257-bin single-frame input, 128-frame
+    minibatches, END TO END through the reference's file formats -- synthetic Pfile pair -> reader / chunker / shuffle ->
+    the BPtrain-compatible binary -> trainer -> .wts file.  (The reference has no CPU trainer; here the step
+    itself runs on the MI355X and the host half is the part that is pinned byte for byte to the reference.)"""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "dnn-for-speech-enhancement_amd", "bptrain")
+    D, nsent, flen = 257, 120, 300
+    rs = np.random.default_rng(3)
+    n = nsent * flen
+
+    def write_pfile(path, data):
+        hdr = ("-pfile_header version 0 size 32768\n-num_sentences %d\n-num_frames %d\n-first_feature_column 2\n"
+               "-num_features %d\n-end\n" % (nsent, n, data.shape[1])).encode()
+        rec = np.empty((n, data.shape[1] + 2), dtype=">u4")
+        rec[:, 0] = np.repeat(np.arange(nsent), flen); rec[:, 1] = np.tile(np.arange(flen), nsent)
+        rec[:, 2:] = data.astype(">f4").view(">u4")
+        with open(path, "wb") as f:
+            f.write(hdr + b"\0" * (32768 - len(hdr))); f.write(rec.tobytes())
+            f.write((np.arange(nsent + 1) * flen).astype(">i4").tobytes())
+
+    with tempfile.TemporaryDirectory() as td:
+        fea = rs.standard_normal((n, D), dtype=np.float32)
+        write_pfile(os.path.join(td, "f.pfile"), fea); write_pfile(os.path.join(td, "t.pfile"), rs.standard_normal((n, D), dtype=np.float32))
+        with open(os.path.join(td, "n.norm"), "w") as f:
+            f.write("<mean>\n" + "".join("%.9g\n" % v for v in fea.mean(0)) + "<inverse std>\n" + "".join("%.9g\n" % v for v in 1.0 / fea.std(0)))
+        args = ["fea_file=%s/f.pfile" % td, "targ_file=%s/t.pfile" % td, "norm_file=%s/n.norm" % td, "outwts_file=%s/w" % td,
+                "log_file=%s/log" % td, "train_sent_range=0-%d" % (nsent - 11), "cv_sent_range=%d-%d" % (nsent - 10, nsent - 1),
+                "fea_dim=257", "fea_context=1", "targ_offset=0", "dropoutflag=0", "traincache=16384", "bunchsize=128", "gpu_used=1",
+                "init_randem_seed=1", "momentum=0.5", "weightcost=0", "lrate=0.01", "visible_omit=0", "hid_omit=0",
+                "layersizes=257,512,257", "activation=sigmoid", "momentum_rule=classic"]
+        t0 = time.perf_counter()
+        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        txt = open(os.path.join(td, "log")).read()
+        m = re.search(r"Training pass: (\d+) samples in ([0-9.]+) s", txt)
+        wts = os.path.getsize(os.path.join(td, "w"))
+    return {"workload": "configs[0] C1: 257->512->257 Sigmoid, 128-frame minibatches, synthetic Pfile pair (120 x 300 frames) -> bptrain -> .wts",
+            "returncode_1_is_success": r.returncode, "train_samples": int(m.group(1)) if m else None,
+            "frames_per_s_reader_upload_gpu": (int(m.group(1)) / float(m.group(2))) if m and float(m.group(2)) > 0 else None,
+            "process_wall_s": wall, "wts_bytes": wts}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -320,6 +366,10 @@ def main():
             res["c5_bf16"] = c5_line(dnnse_amd, dev)
         except Exception as e:
             res["c5_bf16"] = {"error": str(e)[:300]}
+        try:
+            res["c1_end_to_end"] = c1_end_to_end_line()
+        except Exception as e:
+            res["c1_end_to_end"] = {"error": str(e)[:300]}
     if rank == 0:
         if world == 1 and not dp and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(W, b)
