@@ -1102,7 +1102,6 @@ extern "C" int bp_apply_update(bp_handle *h)
 // ------------------------------------------------------------------ in-library data-parallel exchange (bp_dp.h)
 // Rendezvous block in POSIX shared memory ("/bpdp-<key>"): hipIpc handles of every rank + a host barrier.
 struct DpShm {
-    std::atomic<uint32_t> magic;
     std::atomic<int> world;
     std::atomic<int> bar_count, bar_gen;
     std::atomic<int> abort_flag;
@@ -1218,7 +1217,7 @@ extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
     {   // the exchange yields to the GEMMs of the main stream when both have workgroups to place
         int lo_prio = 0, hi_prio = 0;
         DK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-        DK(hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, getenv("BP_DP_COMM_PRIO_NORMAL") ? 0 : lo_prio));
+        DK(hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, lo_prio));
     }
     for (int l = 1; l < h->L; ++l) DK(hipEventCreateWithFlags(&d->ev_g[l], hipEventDisableTiming));
     DK(hipEventCreateWithFlags(&d->ev_comm, hipEventDisableTiming));
