@@ -1205,7 +1205,13 @@ extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
 #define DK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string("bp_dp_attach: ") + #x + ": " + hipGetErrorString(_e); \
         if (d->shm) d->shm->abort_flag.store(1); dp_release(h); return fail(BP_ERR_DEVICE, m); } } while (0)
     // the gradient buffer peers read: fine-grained (uncached in every mapping, written through by the wgrad kernels)
-    DK(hipExtMallocWithFlags((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float), hipDeviceMallocFinegrained));
+    // (if the runtime refuses a fine-grained allocation of this size, an ordinary one still works with the system-scope
+    // loads of bp_dp_reduce_update; the choice is local to this rank)
+    if (hipExtMallocWithFlags((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        d->grad_fine = nullptr;
+        DK(hipMalloc((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float)));
+    }
     DK(hipMemset(d->grad_fine, 0, (h->grad_floats + SLACK) * sizeof(float)));
     d->grad_prev = h->grad; h->grad = d->grad_fine;
     DK(hipExtMallocWithFlags((void **)&d->flags, BP_DP_FLAG_WORDS * sizeof(unsigned), hipDeviceMallocFinegrained));
