@@ -2,7 +2,9 @@
 """bench.py -- training frames/sec of the frame-wise DNN step (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either exactly that -- the script then forks its N ranks itself, rank r on device r % visible devices -- or
+    under a launcher: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...;
+    a --gpus that disagrees with the number of ranks is refused, so an N-GPU line is never printed from fewer ranks)
 
 Workload at every N (weak scaling, per-GPU work fixed): BASELINE.json configs[1] = C2:
 2827->2048->2048->2048->257 (257x11 stacked input), ReLU + dropout 0.1/0.2, fp32, 256 frames
@@ -10,8 +12,10 @@ per GPU per step, lrate 1, momentum 0.5, synthetic N(0,1) frames resident in HBM
 device), Glorot*0.5 weights.  A step = forward + backward + momentum update of one bunch
 (train_bunch_single, BP_GPU.cu:484-673).  For N>1 the global bunch is N*256 frames and the
 gradient exchange is the LIBRARY's own (bp_dp_attach: hipIpc peer reduce-scatter + sharded fused
-update + all-gather, include/bp_c_api.h) -- torch.distributed (gloo) only provides the barrier
-around the timed region and the max over ranks.
+update + all-gather, include/bp_c_api.h; --exchange rccl selects RCCL reduce-scatter/all-gather as the transport of
+the same step) -- the barrier around the timed region and the max over ranks go through the same group's shared-memory
+rendezvous (bp_dp_barrier / bp_dp_allgather); no torch.distributed, no gloo.  The line lists what every rank attached
+to (device ordinal, PCI bus id).
 
 Timing protocol: `prewarm_s` seconds of real, untimed training steps first (a freshly leased GPU
 needs that long to reach its sustained clocks; reported in the line), then W untimed warm-up
@@ -202,7 +206,7 @@ def c1_end_to_end_line():
             "process_wall_s": wall, "wts_bytes": wts}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -211,36 +215,86 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C5 line and the measured peaks")
     ap.add_argument("--chunk", type=int, default=CHUNK)
-    args = ap.parse_args()
+    ap.add_argument("--exchange", choices=["native", "rccl"], default="native",
+                    help="transport of the data-parallel exchange (N > 1): the library's peer kernels, or RCCL reduce-scatter/all-gather")
+    ap.add_argument("--force-dp", action="store_true", help="run the exchange path at N = 1 (world-1 group)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only launch the N ranks, let them meet through the rendezvous and report (no GPU work; CPU-testable)")
+    return ap.parse_args()
 
-    import torch
-    import dnnse_amd
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: fork the N ranks ourselves, one process per GPU (rank r
+    on device r % visible devices), the way `bptrain gpu_used=N` does (donor of the shape: the reference drives its G
+    devices from one host, BP_GPU.cu:29-36,269-277).  The ranks find each other through the library's shared-memory
+    rendezvous; rank 0 prints the JSON line, which is passed through as this process's last stdout line."""
+    import subprocess
+    key = "bench-%d-%d" % (os.getpid(), int(time.time()))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), BENCH_KEY=key, BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None))
+    out0 = procs[0].communicate()[0].decode(errors="replace")
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        sys.exit(1)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)                              # no launcher around us: become one
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    force_dp = os.environ.get("BENCH_FORCE_DP") == "1"      # exercise the exchange path at world size 1
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="gloo")             # barrier + max over ranks only; the exchange is the library's
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
-    ndev = torch.cuda.device_count()
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        # never print an N-GPU line from fewer ranks (or the other way round)
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus, or with no launcher at all" % (args.gpus, world))
+    # the job's rendezvous key: ours when self-launched, else derived from what every rank of a torch.distributed.run
+    # launch shares (master port + the agent's pid)
+    key = os.environ.get("BENCH_KEY") or "bench-%s-%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
+
+    import dnnse_amd
+
+    if args.launch_check:
+        rv = dnnse_amd.Rendezvous(key + "-lc", world, rank, timeout_s=60.0)
+        pids = rv.allgather_f64(float(os.getpid()))
+        rv.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": list(range(world)), "pids": [int(p) for p in pids],
+                              "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+        rv.close()
+        return
+
+    import torch                                              # device synchronisation only; no torch.distributed anywhere
+
+    ndev = dnnse_amd.device_count()
     dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
 
     W, b = dnnse_amd.glorot_net(LAYERS, seed=1, beta=0.5)    # Gen_rand_net flag=1, beta=0.5 recipe
     chunk = max(BUNCH, (args.chunk // BUNCH) * BUNCH)
     kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=20260927, device=dev, max_chunk_frames=chunk)
-    dp = world > 1 or force_dp
+    dp = world > 1 or args.force_dp or os.environ.get("BENCH_FORCE_DP") == "1"
     if dp:
         kw.update(global_bunchsize=BUNCH * world, rank_frame_offset=rank * BUNCH)
     g = dnnse_amd.BP_GPU(world, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, **kw)
+    rank_table = None
     if dp:
-        key = "bench-%s-%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
-        g.dp_attach(world, rank, key)
+        g.dp_attach(world, rank, key, transport=1 if args.exchange == "rccl" else 0)
+        # what each rank attached to, as the library saw it: a reader can check N ranks on N devices
+        rank_table = []
+        for p in range(world):
+            pdev, pci, tr, aq = g.dp_peer_info(p)
+            rank_table.append({"rank": p, "device": pdev, "pci_bus_id": pci})
+        dp_world, dp_rank, _ = g.dp_info()
+        assert dp_world == world and dp_rank == rank
     g.fill_chunk_synthetic(chunk, 20260927 + rank)            # each rank holds its own shard of every bunch
     g.sync()
     nb_chunk = chunk // BUNCH
@@ -248,8 +302,11 @@ def main():
     def barrier():
         g.sync()
         torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+        if dp:
+            g.dp_barrier()                                    # host barrier of the group's rendezvous block
+
+    def max_over_ranks(v):
+        return max(g.dp_allgather_f64(v, world)) if dp else v
 
     def run(nsteps, pos):
         done = 0
@@ -265,11 +322,7 @@ def main():
     if args.prewarm_s > 0:
         pos = run(200, pos); g.sync(); prewarm_steps = 200
         per = (time.perf_counter() - t0) / 200
-        extra = int(max(0.0, args.prewarm_s - (time.perf_counter() - t0)) / per)
-        if dist is not None:                                  # same number of exchanges on every rank
-            tt = torch.tensor([extra], dtype=torch.int64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            extra = int(tt.item())
+        extra = int(max_over_ranks(float(int(max(0.0, args.prewarm_s - (time.perf_counter() - t0)) / per))))   # same number of exchanges on every rank
         if extra > 0:
             pos = run(extra, pos); g.sync(); prewarm_steps += extra
     prewarm_s = time.perf_counter() - t0
@@ -278,12 +331,7 @@ def main():
     t0 = time.perf_counter()
     pos = run(args.steps, pos)
     barrier()
-    dt = time.perf_counter() - t0
-
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     frames = args.steps * BUNCH * world
     value = frames / dt
@@ -296,8 +344,15 @@ def main():
                                "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
                                % (BUNCH, BUNCH * world, chunk),
                    "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world,
-                   "exchange": ("in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)" if dp else "none")},
+                   "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if args.exchange == "rccl" else
+                                 "in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)") if dp else "none"),
+                   "launcher": "self (bench.py forked its ranks)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else
+                               ("torch.distributed.run" if world > 1 else "single process")},
     }
+    if rank_table is not None:
+        res["ranks"] = rank_table
+        res["distinct_devices"] = len(set(r["pci_bus_id"] for r in rank_table))
+        res["dp_acquire_mode"] = g.dp_peer_info(0)[3]
     if rank == 0:
         res["step_frac_of_mfma_peak"] = flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF
     if dp:
@@ -379,9 +434,6 @@ def main():
         except Exception:
             pass
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -30,11 +30,12 @@ LIB_PATH = os.path.join(_PKG_DIR, "libbp_hip.so")
 ABI_SYMBOLS = [
     "bp_last_error", "bp_abi_version", "bp_build_target", "bp_create", "bp_destroy", "bp_train_chunk",
     "bp_cv_chunk", "bp_forward", "bp_get_weights", "bp_get_deltas", "bp_upload_chunk",
-    "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident", "bp_grad_buffer",
-    "bp_apply_update", "bp_dp_forward", "bp_dp_backward_layer", "bp_dp_forward_layer", "bp_dp_dgrads", "bp_dp_wgrad_layer", "bp_apply_update_layer", "bp_advance_step",
-    "bp_grad_layout", "bp_use_grad_buffer", "bp_grad_floats", "bp_read_grads", "bp_write_grads", "bp_set_stream", "bp_last_train_ms", "bp_time_kernel",
+    "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident",
+    "bp_grad_layout", "bp_grad_floats", "bp_read_grads", "bp_read_layer_output", "bp_last_train_ms", "bp_time_kernel",
     "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
-    "bp_set_hyper", "bp_dp_attach", "bp_dp_detach", "bp_dp_info", "bp_profile_step", "bp_measure_peaks", "bp_device_count", "bp_train_resident_masked", "bp_forward_windows",
+    "bp_set_hyper", "bp_dp_attach", "bp_dp_attach_ex", "bp_dp_detach", "bp_dp_info", "bp_dp_peer_info", "bp_dp_barrier", "bp_dp_allgather",
+    "bp_rdv_open", "bp_rdv_barrier", "bp_rdv_allgather", "bp_rdv_close", "bp_device_pci_bus_id",
+    "bp_profile_step", "bp_measure_peaks", "bp_device_count", "bp_train_resident_masked", "bp_forward_windows",
 ]
 PROF_KINDS = ["fwd_l1", "fwd_hidden", "fwd_out", "dgrad_out", "dgrad_hidden", "wgrad_update_grouped"]
 
@@ -97,21 +98,9 @@ def load_library(path=None):
     lib.bp_train_resident.argtypes = [hp, C.c_int, C.c_int]
     lib.bp_sync.argtypes = [hp]
     lib.bp_grads_resident.argtypes = [hp, C.c_int]
-    lib.bp_grad_buffer.argtypes = [hp, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-    lib.bp_apply_update.argtypes = [hp]
-    lib.bp_dp_forward.argtypes = [hp, C.c_int]
-    lib.bp_dp_backward_layer.argtypes = [hp, C.c_int]
-    lib.bp_dp_forward_layer.argtypes = [hp, C.c_int, C.c_int]
-    lib.bp_dp_dgrads.argtypes = [hp]
-    lib.bp_dp_wgrad_layer.argtypes = [hp, C.c_int]
-    lib.bp_apply_update_layer.argtypes = [hp, C.c_int]
-    lib.bp_advance_step.argtypes = [hp]
-    lib.bp_use_grad_buffer.argtypes = [hp, C.c_void_p, C.c_size_t]
     lib.bp_grad_floats.argtypes = [hp, C.POINTER(C.c_size_t)]
     lib.bp_read_grads.argtypes = [hp, fp, C.c_size_t]
-    lib.bp_write_grads.argtypes = [hp, fp, C.c_size_t]
     lib.bp_grad_layout.argtypes = [hp, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
-    lib.bp_set_stream.argtypes = [hp, C.c_void_p]
     lib.bp_last_train_ms.argtypes = [hp, fp, C.POINTER(C.c_int)]
     lib.bp_time_kernel.argtypes = [hp, C.c_int, C.c_int, fp]
     lib.bp_train_resident_masked.argtypes = [hp, C.c_int, C.c_int, C.POINTER(C.POINTER(C.c_uint8))]
@@ -119,6 +108,17 @@ def load_library(path=None):
     lib.bp_measure_peaks.argtypes = [hp, fp, fp]
     lib.bp_set_hyper.argtypes = [hp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float]
     lib.bp_dp_attach.argtypes = [hp, C.c_int, C.c_int, C.c_char_p]
+    lib.bp_dp_attach_ex.argtypes = [hp, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    lib.bp_dp_peer_info.argtypes = [hp, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bp_dp_barrier.argtypes = [hp]
+    lib.bp_dp_allgather.argtypes = [hp, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.bp_rdv_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
+    lib.bp_rdv_barrier.argtypes = [C.c_void_p]
+    lib.bp_rdv_allgather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.bp_rdv_close.argtypes = [C.c_void_p]
+    lib.bp_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    lib.bp_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.bp_read_layer_output.argtypes = [hp, C.c_int, fp, C.c_size_t]
     lib.bp_dp_detach.argtypes = [hp]
     lib.bp_dp_info.argtypes = [hp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint)]
     if path is None:
@@ -303,63 +303,59 @@ class BP_GPU(object):
                 arr[l] = m.ctypes.data_as(P)
         self._check(self._lib.bp_train_resident_masked(self._h, int(first_frame), int(n_frames), arr))
 
+    # ---- gradients without the update (parity tests): bp_grads_resident / bp_read_grads / bp_read_layer_output
     def grads_resident(self, first_frame):
         self._check(self._lib.bp_grads_resident(self._h, int(first_frame)))
-
-    def apply_update(self):
-        self._check(self._lib.bp_apply_update(self._h))
-
-    def dp_forward(self, first_frame):
-        self._check(self._lib.bp_dp_forward(self._h, int(first_frame)))
-
-    def dp_forward_layer(self, first_frame, layer):
-        self._check(self._lib.bp_dp_forward_layer(self._h, int(first_frame), int(layer)))
-
-    def dp_dgrads(self):
-        self._check(self._lib.bp_dp_dgrads(self._h))
-
-    def dp_wgrad_layer(self, layer):
-        self._check(self._lib.bp_dp_wgrad_layer(self._h, int(layer)))
-
-    def dp_backward_layer(self, layer):
-        self._check(self._lib.bp_dp_backward_layer(self._h, int(layer)))
-
-    def apply_update_layer(self, layer):
-        self._check(self._lib.bp_apply_update_layer(self._h, int(layer)))
-
-    def advance_step(self):
-        self._check(self._lib.bp_advance_step(self._h))
-
-    def grad_buffer(self):
-        p, n = C.c_void_p(), C.c_size_t()
-        self._check(self._lib.bp_grad_buffer(self._h, C.byref(p), C.byref(n)))
-        return p.value, n.value
 
     def grad_floats(self):
         n = C.c_size_t()
         self._check(self._lib.bp_grad_floats(self._h, C.byref(n)))
         return n.value
 
-    def use_grad_buffer(self, device_ptr, n_floats):
-        self._check(self._lib.bp_use_grad_buffer(self._h, C.c_void_p(device_ptr), int(n_floats)))
-
-    def read_grads(self):
-        g = np.empty(self.grad_floats(), np.float32)
-        self._check(self._lib.bp_read_grads(self._h, _fp(g), g.size))
-        return g
-
-    def write_grads(self, g):
-        g = np.ascontiguousarray(g, dtype=np.float32)
-        self._check(self._lib.bp_write_grads(self._h, _fp(g), g.size))
-
     def grad_layout(self, layer):
         o, c = C.c_size_t(), C.c_size_t()
         self._check(self._lib.bp_grad_layout(self._h, int(layer), C.byref(o), C.byref(c)))
         return o.value, c.value
 
+    def read_grads(self):
+        """Per-layer weight / bias gradients of the last bp_grads_resident, unpadded: ([None, G_1 [prev][cur], ...], [None, gb_1, ...])."""
+        g = np.empty(self.grad_floats(), np.float32)
+        self._check(self._lib.bp_read_grads(self._h, _fp(g), g.size))
+        pad = lambda v: (v + 63) & ~63
+        gw, gb = [None], [None]
+        for l in range(1, self.numlayers):
+            off, cnt = self.grad_layout(l)
+            lp, lc = pad(self.layersizes[l - 1]), pad(self.layersizes[l])
+            assert cnt == lp * lc + lc
+            gw.append(g[off:off + lp * lc].reshape(lp, lc)[:self.layersizes[l - 1], :self.layersizes[l]].copy())
+            gb.append(g[off + lp * lc:off + cnt][:self.layersizes[l]].copy())
+        return gw, gb
+
+    def read_layer_output(self, layer):
+        y = np.empty((self.bunchsize, self.layersizes[layer]), np.float32)
+        self._check(self._lib.bp_read_layer_output(self._h, int(layer), _fp(y), y.size))
+        return y
+
     # ---- in-library data-parallel exchange (bp_dp_attach, include/bp_c_api.h)
-    def dp_attach(self, world, rank, key):
-        self._check(self._lib.bp_dp_attach(self._h, int(world), int(rank), str(key).encode()))
+    def dp_attach(self, world, rank, key, transport=0):
+        """transport: 0 = the library's peer kernels over hipIpc mappings, 1 = RCCL reduce-scatter / all-gather."""
+        self._check(self._lib.bp_dp_attach_ex(self._h, int(world), int(rank), str(key).encode(), int(transport)))
+
+    def dp_peer_info(self, peer):
+        """(device ordinal in the peer's process, PCI bus id, transport, acquire mode) of rank `peer`."""
+        dev, tr, aq = C.c_int(), C.c_int(), C.c_int()
+        buf = C.create_string_buffer(32)
+        self._check(self._lib.bp_dp_peer_info(self._h, int(peer), C.byref(dev), buf, 32, C.byref(tr), C.byref(aq)))
+        return int(dev.value), buf.value.decode(), int(tr.value), int(aq.value)
+
+    def dp_barrier(self):
+        self._check(self._lib.bp_dp_barrier(self._h))
+
+    def dp_allgather_f64(self, value, world):
+        mine = (C.c_double * 1)(float(value))
+        out = (C.c_double * int(world))()
+        self._check(self._lib.bp_dp_allgather(self._h, mine, 8, out))
+        return [float(v) for v in out]
 
     def dp_detach(self):
         self._check(self._lib.bp_dp_detach(self._h))
@@ -368,9 +364,6 @@ class BP_GPU(object):
         w, r, n = C.c_int(), C.c_int(), C.c_uint()
         self._check(self._lib.bp_dp_info(self._h, C.byref(w), C.byref(r), C.byref(n)))
         return int(w.value), int(r.value), int(n.value)
-
-    def set_stream(self, hip_stream_ptr):
-        self._check(self._lib.bp_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
 
     def sync(self):
         self._check(self._lib.bp_sync(self._h))
@@ -407,3 +400,47 @@ class BP_GPU(object):
             self.close()
         except Exception:
             pass
+
+
+def device_count():
+    n = C.c_int()
+    lib = load_library()
+    if lib.bp_device_count(C.byref(n)) != 0:
+        raise BPError(lib.bp_last_error().decode())
+    return int(n.value)
+
+
+def device_pci_bus_id(device):
+    lib = load_library()
+    buf = C.create_string_buffer(32)
+    if lib.bp_device_pci_bus_id(int(device), buf, 32) != 0:
+        raise BPError(lib.bp_last_error().decode())
+    return buf.value.decode()
+
+
+class Rendezvous(object):
+    """bp_rdv_* (include/bp_c_api.h): the host-only rendezvous of the data-parallel ranks; works without a GPU."""
+
+    def __init__(self, key, world, rank, timeout_s=30.0):
+        self._lib = load_library()
+        self.world, self.rank = int(world), int(rank)
+        self._r = C.c_void_p()
+        if self._lib.bp_rdv_open(str(key).encode(), self.world, self.rank, float(timeout_s), C.byref(self._r)) != 0:
+            self._r = None
+            raise BPError(self._lib.bp_last_error().decode())
+
+    def barrier(self):
+        if self._lib.bp_rdv_barrier(self._r) != 0:
+            raise BPError(self._lib.bp_last_error().decode())
+
+    def allgather_f64(self, value):
+        mine = (C.c_double * 1)(float(value))
+        out = (C.c_double * self.world)()
+        if self._lib.bp_rdv_allgather(self._r, mine, 8, out) != 0:
+            raise BPError(self._lib.bp_last_error().decode())
+        return [float(v) for v in out]
+
+    def close(self):
+        if self._r is not None:
+            self._lib.bp_rdv_close(self._r)
+            self._r = None

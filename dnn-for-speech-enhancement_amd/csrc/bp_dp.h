@@ -33,7 +33,7 @@
 
 enum { BP_DP_MAXRANKS = 8 };
 // flag words of one rank: [kind][layer][source rank]
-enum { BP_DP_FLAG_GRAD = 0, BP_DP_FLAG_W = 1, BP_DP_FLAG_KINDS = 2 };
+enum { BP_DP_FLAG_GRAD = 0, BP_DP_FLAG_W = 1, BP_DP_FLAG_PROBE = 2 /* attach-time self-test: layer index = direction */, BP_DP_FLAG_KINDS = 3 };
 #define BP_DP_FLAG_WORDS (BP_DP_FLAG_KINDS * 16 * BP_DP_MAXRANKS)
 __host__ __device__ inline int bp_dp_flag_index(int kind, int layer, int src) { return (kind * 16 + layer) * BP_DP_MAXRANKS + src; }
 
@@ -161,4 +161,82 @@ __global__ void bp_dp_copy(float *dst, const float *src, unsigned long long n4)
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long q = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride)
         reinterpret_cast<float4 *>(dst)[q] = reinterpret_cast<const float4 *>(src)[q];
+}
+
+
+// ------------------------------------------------------------------ attach-time self-test of the memory-model contract
+// The exchange above leans on two properties of the platform that cannot be derived from the programming model alone
+// (header comment): (W) weights a PEER writes into this rank's cacheable arena with system-scope write-through stores are
+// what this rank's next kernels read with plain cached loads once its flag has risen; (G) gradients this rank's kernels
+// wrote with plain stores into fine-grained memory are what a peer's system-scope loads return once ITS flag has risen.
+// bp_dp_attach checks both on the actual devices of the group, with the product's own access flavours and ordering
+// recipe, on probe buffers of the same allocation kinds, before any training step relies on them (bp_engine.hip,
+// dp_selftest).  If (W) fails as is, the group falls back to an explicit system-scope acquire on every XCD behind each
+// wait (bp_dp_l2_invalidate); if it still fails, bp_dp_attach fails.
+#define BP_DP_PROBE_FLOATS (64 * 1024)            /* 256 KB per probe buffer */
+__device__ __forceinline__ float bp_probe_value(unsigned round, unsigned writer, unsigned idx)
+{
+    return (float)((round * 131u + writer * 17u + idx * 3u) & 0xFFFFFu);
+}
+// plain cached reads of the whole probe from every XCD (leaves its lines in the L2s / L1s of this device)
+__global__ void bp_dp_probe_touch(const float *probe, float *sink)
+{
+    float s = 0.f;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < BP_DP_PROBE_FLOATS; i += gridDim.x * blockDim.x) s += probe[i];
+    if (s == 1.2345e-30f) *sink = s;
+}
+// writer `rank` fills ITS slice of every rank's probe with system-scope write-through 16-byte stores, drains, and raises
+// word (PROBE, 0, rank) of every rank's flag array: the product's all-gather recipe (bp_dp_reduce_update).  One workgroup.
+__global__ __launch_bounds__(256) void bp_dp_probe_push(DpReduceArgs a, unsigned round)
+{
+    const unsigned per = BP_DP_PROBE_FLOATS / BP_DP_MAXRANKS, lo = a.rank * per;
+    for (int p = 0; p < a.world; ++p) {
+        __amdgpu_buffer_rsrc_t rw = bp_rsrc(a.params[p] + lo, per * 4);
+        for (unsigned q = threadIdx.x; q < per / 4; q += blockDim.x) {
+            bp_f32x4 v;
+            v.x = bp_probe_value(round, a.rank, lo + 4 * q); v.y = bp_probe_value(round, a.rank, lo + 4 * q + 1);
+            v.z = bp_probe_value(round, a.rank, lo + 4 * q + 2); v.w = bp_probe_value(round, a.rank, lo + 4 * q + 3);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rw, q * 16, 0, BP_AUX_SYS);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if ((int)threadIdx.x < a.world)
+        __hip_atomic_store(a.peers.flags[threadIdx.x] + a.flag_index, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// owner: plain cached loads of the whole probe; counts words that are not what writer (idx / per) stored in `round`
+__global__ void bp_dp_probe_check(const float *probe, int world, unsigned round, unsigned *bad)
+{
+    const unsigned per = BP_DP_PROBE_FLOATS / BP_DP_MAXRANKS;
+    unsigned n = 0;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < per * (unsigned)world; i += gridDim.x * blockDim.x)
+        if (probe[i] != bp_probe_value(round, i / per, i)) ++n;
+    if (n) atomicAdd(bad, n);
+}
+// owner: plain stores of a fresh pattern into its own fine-grained probe (what the wgrad kernels do to the gradient buffer)
+__global__ void bp_dp_probe_fill(float *probe, unsigned round, unsigned rank)
+{
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < BP_DP_PROBE_FLOATS; i += gridDim.x * blockDim.x)
+        probe[i] = bp_probe_value(round, rank, i);
+}
+// reader: system-scope 16-byte loads of slice `rank` of every rank's fine-grained probe (the reduce-scatter read)
+__global__ void bp_dp_probe_check_remote(DpReduceArgs a, unsigned round, unsigned *bad)
+{
+    const unsigned per = BP_DP_PROBE_FLOATS / BP_DP_MAXRANKS, lo = a.rank * per;
+    unsigned n = 0;
+    for (int p = 0; p < a.world; ++p) {
+        __amdgpu_buffer_rsrc_t rg = bp_rsrc(a.grads[p] + lo, per * 4);
+        for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < per / 4; q += gridDim.x * blockDim.x) {
+            const bp_f32x4 v = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, q * 16, 0, BP_AUX_SYS));
+            n += v.x != bp_probe_value(round, p, lo + 4 * q) || v.y != bp_probe_value(round, p, lo + 4 * q + 1) ||
+                 v.z != bp_probe_value(round, p, lo + 4 * q + 2) || v.w != bp_probe_value(round, p, lo + 4 * q + 3);
+        }
+    }
+    if (n) atomicAdd(bad, n);
+}
+// Fallback acquire (dp "acquire mode" 1): one system-scope acquire (buffer_inv sc0 sc1) per workgroup; the launch has
+// enough workgroups to land on every XCD, so every L2 of this device drops its non-coherent lines before the next kernel.
+__global__ void bp_dp_l2_invalidate()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }

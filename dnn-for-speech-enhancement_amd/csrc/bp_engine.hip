@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cmath>
 #include <string>
 #include <utility>
 #include <vector>
@@ -20,14 +21,12 @@
 #include "bp_kernels.h"
 #include "bp_bf16.h"
 #include "bp_dp.h"
+#include "bp_rdv.h"
 #include "bp_wgrad_dma.h"
 
-#include <atomic>
-#include <chrono>
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
+#include <dlfcn.h>
+
+struct ncclUniqueIdBytes { char internal[128]; };   // = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -65,7 +64,6 @@ struct bp_handle {
     float *out_chunk;            // device: network outputs of a whole chunk [frames][ld_L] (CV / forward), grow-only
     size_t out_chunk_frames;
     uint32_t step;               // bunches trained so far (dropout stream position)
-    int dp_first, dp_next_layer, dp_fwd_next; // layer-by-layer data-parallel step in progress
     long mask_lo, mask_hi; uint32_t mask_step0;
     uint32_t th_vis, th_hid;
     hipEvent_t ev0, ev1; float last_ms; int last_bunches;
@@ -116,7 +114,7 @@ static uint32_t drop_threshold(float p)
 }
 
 extern "C" const char *bp_last_error(void) { return g_err.c_str(); }
-extern "C" int bp_abi_version(void) { return 3; }   // 3: bp_dp_attach (in-library exchange), bp_set_hyper, bp_profile_step
+extern "C" int bp_abi_version(void) { return 4; }   // 4: host-driven DP split removed; bp_rdv_*, bp_dp_attach_ex (RCCL transport), bp_dp_peer_info
 extern "C" const char *bp_build_target(void) { return "gfx950"; }
 extern "C" int bp_device_count(int *n)
 {
@@ -163,8 +161,8 @@ extern "C" int bp_destroy(bp_handle *h)
     return BP_OK;
 }
 
-extern "C" int bp_dp_detach(bp_handle *h);
 static int dp_check(bp_handle *h);
+static int check_hyper(float, float, float, int, float, float, const char *);
 static hipError_t dp_bunch(bp_handle *h, int first);
 static hipError_t dp_flush(bp_handle *h);
 static int dp_gather_deltas(bp_handle *h);
@@ -181,6 +179,10 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     if (cfg->bunchsize < 1) return fail(BP_ERR_ARG, "bp_create: bunchsize must be >= 1");
     if (cfg->gpu_used < 1) return fail(BP_ERR_ARG, "bp_create: gpu_used must be >= 1");  // BP_GPU.cu:20-24
     if (cfg->compute_dtype != 0 && cfg->compute_dtype != 1) return fail(BP_ERR_ARG, "bp_create: compute_dtype must be 0 (fp32) or 1 (bf16)");
+    {
+        const int r = check_hyper(cfg->lrate, cfg->momentum, cfg->weightcost, cfg->dropoutflag, cfg->visible_omit, cfg->hid_omit, "bp_create");
+        if (r != BP_OK) return r;
+    }
     for (int l = 0; l < cfg->numlayers; ++l)
         if (cfg->layersizes[l] < 1) return fail(BP_ERR_ARG, "bp_create: layer size must be >= 1");
     int ndev = 0;
@@ -197,7 +199,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->cap = cfg->max_chunk_frames > 0 ? cfg->max_chunk_frames : BP_MAXCACHEFRAME;
     if (h->cap < h->B) h->cap = h->B;
     h->chunk_frames = 0;
-    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0; h->dp_first = 0; h->dp_next_layer = 0; h->dp_fwd_next = 0;
+    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0;
     h->th_vis = cfg->dropoutflag == 1 ? drop_threshold(cfg->visible_omit) : 0u;
     h->th_hid = cfg->dropoutflag == 1 ? drop_threshold(cfg->hid_omit) : 0u;
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
@@ -273,31 +275,37 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     return BP_OK;
 }
 
+// lrate / momentum / weightcost must be finite; with dropout on, the omit rates must lie in [0, 1): a rate of 1 would
+// make the CV keep-scale 0 and a rate outside the range wraps the 32-bit drop threshold.
+static int check_hyper(float lrate, float momentum, float weightcost, int dropoutflag, float visible_omit, float hid_omit, const char *who)
+{
+    if (!(lrate == lrate && momentum == momentum && weightcost == weightcost) || std::isinf(lrate) || std::isinf(momentum) || std::isinf(weightcost))
+        return fail(BP_ERR_ARG, std::string(who) + ": lrate / momentum / weightcost must be finite");
+    if (dropoutflag == 1 && !(visible_omit >= 0.0f && visible_omit < 1.0f && hid_omit >= 0.0f && hid_omit < 1.0f))
+        return fail(BP_ERR_ARG, std::string(who) + ": visible_omit and hid_omit must be in [0, 1) when dropoutflag is 1");
+    return BP_OK;
+}
+
 extern "C" int bp_set_hyper(bp_handle *h, float lrate, float momentum, float weightcost, int dropoutflag, float visible_omit,
                             float hid_omit)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
+    int r = check_hyper(lrate, momentum, weightcost, dropoutflag, visible_omit, hid_omit, "bp_set_hyper");
+    if (r != BP_OK) return r;
     h->cfg.lrate = lrate; h->cfg.momentum = momentum; h->cfg.weightcost = weightcost;
     if (dropoutflag != h->cfg.dropoutflag || visible_omit != h->cfg.visible_omit || hid_omit != h->cfg.hid_omit) {
         HIPCHK(hipSetDevice(h->cfg.device));
-        h->cfg.dropoutflag = dropoutflag; h->cfg.visible_omit = visible_omit; h->cfg.hid_omit = hid_omit;
-        h->th_vis = dropoutflag == 1 ? drop_threshold(visible_omit) : 0u;
-        h->th_hid = dropoutflag == 1 ? drop_threshold(hid_omit) : 0u;
-        if (h->th_vis && !h->in_drop) {
-            int r = dev_alloc(h, &h->in_drop, ((size_t)h->cap + 64) * h->ld[0]);
+        const uint32_t th_vis = dropoutflag == 1 ? drop_threshold(visible_omit) : 0u;
+        if (th_vis && !h->in_drop) {
+            HIPCHK(hipStreamSynchronize(h->stream));            // (an allocation in the middle of queued bunches: drain first)
+            r = dev_alloc(h, &h->in_drop, ((size_t)h->cap + 64) * h->ld[0]);
             if (r != BP_OK) return r;
         }
+        h->cfg.dropoutflag = dropoutflag; h->cfg.visible_omit = visible_omit; h->cfg.hid_omit = hid_omit;
+        h->th_vis = th_vis;
+        h->th_hid = dropoutflag == 1 ? drop_threshold(hid_omit) : 0u;
         h->mask_lo = h->mask_hi = -1;
     }
-    return BP_OK;
-}
-
-extern "C" int bp_set_stream(bp_handle *h, void *hip_stream)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return BP_OK;
 }
 
@@ -909,121 +917,34 @@ extern "C" int bp_train_resident_masked(bp_handle *h, int first_frame, int n_fra
     return rc;
 }
 
-// ------------------------------------------------------------------ data-parallel split
-static hipError_t dp_input(bp_handle *h, int first, const float **x0)
-{
-    *x0 = h->in + (size_t)first * h->ld[0];
-    if (use_mask(h)) {
-        const int B = h->B;
-        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
-                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
-                        (first - h->mask_lo) % B == 0;
-        if (!ok) { hipError_t er = mask_range(h, first, B); if (er != hipSuccess) return er; }
-        *x0 = h->in_drop + (size_t)first * h->ld[0];
-    }
-    return hipSuccess;
-}
-
-extern "C" int bp_dp_forward_layer(bp_handle *h, int first_frame, int layer)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_forward_layer: layer out of range");
-    if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
-        return fail(BP_ERR_ARG, "bp_dp_forward_layer: bunch outside the resident chunk");
-    if (layer != 1 && (h->dp_fwd_next != layer || h->dp_first != first_frame))
-        return fail(BP_ERR_STATE, "bp_dp_forward_layer: layers must be called 1 ... numlayers-1 for one bunch");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
-    const float *x0;
-    HIPCHK(dp_input(h, first_frame, &x0));
-    const float *tg = h->targ + (size_t)first_frame * h->ld[h->L - 1];
-    if (h->bf) {
-        if (layer == 1) HIPCHK(bf_input(h, x0, h->B));
-        HIPCHK(bf_fwd(h, layer, h->B, tg, nullptr, true, 1.0f));
-    } else {
-        HIPCHK(launch_fwd(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], tg, nullptr, true, 1.0f));
-    }
-    h->dp_first = first_frame; h->dp_fwd_next = layer + 1;
-    h->dp_next_layer = (layer == h->L - 1) ? h->L - 1 : 0;     // backward may start after the output layer
-    return BP_OK;
-}
-
-extern "C" int bp_dp_forward(bp_handle *h, int first_frame)
-{
-    int r = BP_OK;
-    for (int l = 1; h && r == BP_OK && l < h->L; ++l) r = bp_dp_forward_layer(h, first_frame, l);
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    return r;
-}
-
-extern "C" int bp_dp_dgrads(bp_handle *h)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (h->dp_next_layer != h->L - 1) return fail(BP_ERR_STATE, "bp_dp_dgrads: run the forward of a bunch first");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    for (int l = h->L - 1; l >= 2; --l) {
-        if (h->bf) HIPCHK(bf_dgrad(h, l)); else HIPCHK(launch_dgrad(h, h->stream, l, h->B));
-    }
-    h->dp_next_layer = -1;                                     // wgrads may now come in any order
-    return BP_OK;
-}
-
-extern "C" int bp_dp_wgrad_layer(bp_handle *h, int layer)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_wgrad_layer: layer out of range");
-    if (h->dp_next_layer != -1) return fail(BP_ERR_STATE, "bp_dp_wgrad_layer: call bp_dp_dgrads first");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->bf) { HIPCHK(bf_wgrad(h, layer, false)); return BP_OK; }
-    const float *x0;
-    HIPCHK(dp_input(h, h->dp_first, &x0));
-    HIPCHK(launch_wgrad(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], false));
-    return BP_OK;
-}
-
-extern "C" int bp_dp_backward_layer(bp_handle *h, int layer)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (layer < 1 || layer >= h->L) return fail(BP_ERR_ARG, "bp_dp_backward_layer: layer out of range");
-    if (layer != h->dp_next_layer)
-        return fail(BP_ERR_STATE, "bp_dp_backward_layer: call bp_dp_forward first, then layers numlayers-1 ... 1 in order");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    if (h->bf) {
-        if (layer != 1) HIPCHK(bf_dgrad(h, layer));
-        HIPCHK(bf_wgrad(h, layer, false));
-        h->dp_next_layer = layer - 1;
-        return BP_OK;
-    }
-    const float *x0;
-    HIPCHK(dp_input(h, h->dp_first, &x0));
-    if (layer != 1) HIPCHK(launch_dgrad(h, h->stream, layer, h->B));
-    HIPCHK(launch_wgrad(h, h->stream, layer, h->B, layer == 1 ? x0 : h->y[layer - 1], false));
-    h->dp_next_layer = layer - 1;
-    return BP_OK;
-}
-
+// ------------------------------------------------------------------ gradients without the update (parity tests)
+// forward + backward of ONE local bunch with the weight gradients stored into the flat buffer [W_1|b_1|W_2|b_2|...]
+// instead of being applied: the kernels of the data-parallel step (wgrad "store" form), exposed so that a test can
+// compare the gradient itself with the oracle's.  State (weights, momentum, step counter) is untouched.
+static hipError_t bunch(bp_handle *h, int first, bool fused);
 extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
 {
-    int r = bp_dp_forward(h, first_frame);
-    for (int l = h ? h->L - 1 : 0; r == BP_OK && l >= 1; --l) r = bp_dp_backward_layer(h, l);
-    return r;
-}
-
-extern "C" int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats)
-{
-    if (!h || !device_ptr || !n_floats) return fail(BP_ERR_ARG, "null argument");
-    if (!h->grad) { HIPCHK(hipSetDevice(h->cfg.device)); int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
-    *device_ptr = h->grad; *n_floats = h->grad_floats;
+    if (!h) return fail(BP_ERR_ARG, "null handle");
+    if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
+        return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
+    if (h->dp) return fail(BP_ERR_STATE, "bp_grads_resident: not on an attached handle (the exchange owns the gradient buffer)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
+    HIPCHK(bunch(h, first_frame, false));
     return BP_OK;
 }
-
 extern "C" int bp_grad_floats(bp_handle *h, size_t *n_floats)
 {
     if (!h || !n_floats) return fail(BP_ERR_ARG, "null argument");
     *n_floats = h->grad_floats;
     return BP_OK;
 }
-
+extern "C" int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *count)
+{
+    if (!h || layer < 1 || layer >= h->L || !offset || !count) return fail(BP_ERR_ARG, "bp_grad_layout: bad argument");
+    *offset = h->g_off[layer]; *count = h->g_cnt[layer];
+    return BP_OK;
+}
 extern "C" int bp_read_grads(bp_handle *h, float *host_dst, size_t n_floats)
 {
     if (!h || !host_dst) return fail(BP_ERR_ARG, "null argument");
@@ -1035,111 +956,94 @@ extern "C" int bp_read_grads(bp_handle *h, float *host_dst, size_t n_floats)
     return BP_OK;
 }
 
-extern "C" int bp_write_grads(bp_handle *h, const float *host_src, size_t n_floats)
+// Hidden-layer outputs y_l (post-activation, post-dropout: layer_y, BP_GPU.h:27) of the bunch processed last, as
+// [bunchsize][layersizes[layer]] without padding: lets a parity test see WHICH units are on (ReLU decisions that fall
+// within rounding of zero are summation-order dependent; tests/test_gpu_parity.py counts them).  fp32 handles.
+extern "C" int bp_read_layer_output(bp_handle *h, int layer, float *host_dst, size_t n_floats)
 {
-    if (!h || !host_src) return fail(BP_ERR_ARG, "null argument");
-    if (n_floats != h->grad_floats) return fail(BP_ERR_ARG, "bp_write_grads: size must equal bp_grad_floats");
+    if (!h || !host_dst) return fail(BP_ERR_ARG, "null argument");
+    if (h->bf) return fail(BP_ERR_STATE, "bp_read_layer_output: fp32 handles only");
+    if (layer < 1 || layer >= h->L - 1) return fail(BP_ERR_ARG, "bp_read_layer_output: hidden layers 1 .. numlayers-2 only");
+    if (n_floats != (size_t)h->B * h->s[layer]) return fail(BP_ERR_ARG, "bp_read_layer_output: size must be bunchsize*layersizes[layer]");
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
-    HIPCHK(hipMemcpyAsync(h->grad, host_src, n_floats * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(host_dst, (size_t)h->s[layer] * 4, h->y[layer], (size_t)h->ld[layer] * 4, (size_t)h->s[layer] * 4, h->B,
+                            hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return BP_OK;
 }
 
-extern "C" int bp_use_grad_buffer(bp_handle *h, void *device_ptr, size_t n_floats)
+// ------------------------------------------------------------------ host rendezvous (bp_rdv.h), C ABI
+extern "C" int bp_rdv_open(const char *key, int world, int rank, double timeout_s, bp_rdv **out)
 {
-    if (!h || !device_ptr) return fail(BP_ERR_ARG, "null argument");
-    if (n_floats != h->grad_floats) return fail(BP_ERR_ARG, "bp_use_grad_buffer: size must equal bp_grad_floats");
-    if (((uintptr_t)device_ptr & 15) != 0) return fail(BP_ERR_ARG, "bp_use_grad_buffer: pointer must be 16-byte aligned");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->grad = (float *)device_ptr;        // not in h->allocs: never freed here
+    const int rc = rdv_open(key, world, rank, timeout_s, out);
+    return rc == 0 ? BP_OK : fail(rc, g_rdv_err);
+}
+extern "C" int bp_rdv_barrier(bp_rdv *r)
+{
+    if (!r) return fail(BP_ERR_ARG, "null rendezvous");
+    const int rc = rdv_barrier(r);
+    return rc == 0 ? BP_OK : fail(rc, g_rdv_err);
+}
+extern "C" int bp_rdv_allgather(bp_rdv *r, const void *mine, size_t bytes, void *all)
+{
+    if (!r || !mine || !all) return fail(BP_ERR_ARG, "null argument");
+    const int rc = rdv_allgather(r, mine, bytes, all);
+    return rc == 0 ? BP_OK : fail(rc, g_rdv_err);
+}
+extern "C" int bp_rdv_close(bp_rdv *r) { rdv_close(r, false); return BP_OK; }
+
+extern "C" int bp_device_pci_bus_id(int device, char *buf, int len)
+{
+    if (!buf || len < 16) return fail(BP_ERR_ARG, "bp_device_pci_bus_id: buffer of at least 16 bytes needed");
+    HIPCHK(hipDeviceGetPCIBusId(buf, len, device));
     return BP_OK;
 }
-
-extern "C" int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *count)
-{
-    if (!h || layer < 1 || layer >= h->L || !offset || !count) return fail(BP_ERR_ARG, "bp_grad_layout: bad argument");
-    *offset = h->g_off[layer]; *count = h->g_cnt[layer];
-    return BP_OK;
-}
-
-extern "C" int bp_apply_update_layer(bp_handle *h, int l)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (l < 1 || l >= h->L) return fail(BP_ERR_ARG, "bp_apply_update_layer: layer out of range");
-    if (!h->grad) return fail(BP_ERR_STATE, "bp_apply_update_layer: no gradients (call bp_grads_resident first)");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    const float m = h->cfg.momentum, lr = h->cfg.lrate;
-    const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
-    const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
-    const float *g = h->grad + h->g_off[l];
-    hipLaunchKernelGGL(bp_update_flat, dim3(2048), dim3(256), 0, h->stream, h->W[l], h->dW[l], g, nw, h->b[l], h->db[l],
-                       g + nw, h->ld[l], m, c1, h->cfg.weightcost, (float)h->Bg);
-    HIPCHK(hipGetLastError());
-    if (h->bf) HIPCHK(bf_shadow(h, l));          // refresh the bf16 copies the next forward / dgrad read
-    return BP_OK;
-}
-
-extern "C" int bp_advance_step(bp_handle *h)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    h->step++;
-    return BP_OK;
-}
-
-extern "C" int bp_apply_update(bp_handle *h)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    for (int l = h->L - 1; l >= 1; --l) {
-        int r = bp_apply_update_layer(h, l);
-        if (r != BP_OK) return r;
-    }
-    return bp_advance_step(h);
-}
-
 
 // ------------------------------------------------------------------ in-library data-parallel exchange (bp_dp.h)
-// Rendezvous block in POSIX shared memory ("/bpdp-<key>"): hipIpc handles of every rank + a host barrier.
-struct DpShm {
-    std::atomic<int> world;
-    std::atomic<int> bar_count, bar_gen;
-    std::atomic<int> abort_flag;
-    int device[BP_DP_MAXRANKS], pid[BP_DP_MAXRANKS];
-    hipIpcMemHandle_t params[BP_DP_MAXRANKS], grad[BP_DP_MAXRANKS], deltas[BP_DP_MAXRANKS], flags[BP_DP_MAXRANKS];
+// What every rank publishes through the rendezvous block (RdvShm::blob).
+struct DpBlob {
+    int device; char pci[20];
+    hipIpcMemHandle_t params, grad, deltas, flags, probe_p, probe_g;
 };
+static_assert(sizeof(DpBlob) <= BP_RDV_BLOB_BYTES, "rendezvous blob too small");
+
+// RCCL transport (north_star names it): resolved at run time from librccl.so so that the library itself
+// carries no link dependency on it.  Signatures from rccl.h (ROCm 7.2).
+struct RcclApi {
+    void *lib;
+    int (*GetUniqueId)(void *id);
+    int (*CommInitRank)(void **comm, int nranks, ncclUniqueIdBytes id, int rank);
+    int (*ReduceScatter)(const void *send, void *recv, size_t recvcount, int dtype, int op, void *comm, hipStream_t st);
+    int (*AllGather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t st);
+    int (*CommDestroy)(void *comm);
+    const char *(*GetErrorString)(int);
+};
+
 struct bp_dp {
     int world, rank;
-    DpShm *shm; std::string shm_name;
+    bp_rdv *rdv;
+    int backend;                  // 0: native peer kernels over hipIpc mappings | 1: RCCL reduce-scatter / all-gather
+    int acquire_mode;             // 0: kernel boundary behind the wait kernel | 1: + explicit system-scope acquire on every XCD
+    bool distinct_devices;        // at least two ranks sit on different physical devices
+    int peer_device[BP_DP_MAXRANKS]; char peer_pci[BP_DP_MAXRANKS][20];
     float *p_params[BP_DP_MAXRANKS], *p_grad[BP_DP_MAXRANKS], *p_deltas[BP_DP_MAXRANKS];
+    float *p_probe_p[BP_DP_MAXRANKS], *p_probe_g[BP_DP_MAXRANKS];
     unsigned *p_flags[BP_DP_MAXRANKS];
     float *grad_fine, *grad_prev; // fine-grained gradient buffer used while attached / the handle's own one (restored at detach)
+    float *probe_p, *probe_g;     // self-test probes: ordinary (like the parameter arena) / fine-grained (like the gradient buffer)
     unsigned *flags;              // own flag words (fine-grained device memory, exported)
     unsigned *arrive;             // [BP_MAXLAYER] last-arriver counters of bp_dp_reduce_update
     unsigned *err;                // pinned host word the wait kernels raise on timeout
     hipStream_t comm;             // exchange stream: signal -> wait -> reduce/update/all-gather per layer
     hipEvent_t ev_g[BP_MAXLAYER]; // main stream: gradient segment l is complete
+    hipEvent_t ev_w[BP_MAXLAYER]; // comm stream (RCCL backend): the weights of layer l have been gathered
     hipEvent_t ev_comm;           // comm stream: everything queued so far is done (flush)
     unsigned epoch;               // minibatches exchanged so far (flag value of the current one)
     size_t lo[BP_MAXLAYER], hi[BP_MAXLAYER];   // this rank's slice of layer l's flat segment
     unsigned long long budget_ticks;
     bool peers_open;
+    RcclApi rccl; void *rccl_comm; float *red;   // RCCL backend: communicator, reduce-scatter landing buffer (largest slice)
 };
-
-static int dp_host_barrier(bp_dp *d, double timeout_s)
-{
-    DpShm *s = d->shm;
-    const int gen = s->bar_gen.load();
-    if (s->bar_count.fetch_add(1) + 1 == d->world) { s->bar_count.store(0); s->bar_gen.fetch_add(1); return BP_OK; }
-    const auto t0 = std::chrono::steady_clock::now();
-    while (s->bar_gen.load() == gen) {
-        if (s->abort_flag.load()) return fail(BP_ERR_STATE, "data-parallel group: a peer rank failed");
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-            return fail(BP_ERR_STATE, "data-parallel group: host barrier timed out (a rank is missing)");
-        usleep(100);
-    }
-    return BP_OK;
-}
 
 static double dp_timeout_s()
 {
@@ -1148,28 +1052,29 @@ static double dp_timeout_s()
     return v > 0.5 ? v : 0.5;
 }
 
-static void dp_release(bp_handle *h)
+static void dp_release(bp_handle *h, bool failed)
 {
     bp_dp *d = h->dp;
     if (!d) return;
     if (d->comm) (void)hipStreamSynchronize(d->comm);
+    if (d->rccl_comm && d->rccl.CommDestroy) (void)d->rccl.CommDestroy(d->rccl_comm);
+    if (d->rccl.lib) dlclose(d->rccl.lib);
     if (d->peers_open)
         for (int p = 0; p < d->world; ++p) {
             if (p == d->rank) continue;
-            if (d->p_params[p]) (void)hipIpcCloseMemHandle(d->p_params[p]);
-            if (d->p_grad[p]) (void)hipIpcCloseMemHandle(d->p_grad[p]);
-            if (d->p_deltas[p]) (void)hipIpcCloseMemHandle(d->p_deltas[p]);
-            if (d->p_flags[p]) (void)hipIpcCloseMemHandle(d->p_flags[p]);
+            for (void *q : {(void *)d->p_params[p], (void *)d->p_grad[p], (void *)d->p_deltas[p], (void *)d->p_flags[p],
+                            (void *)d->p_probe_p[p], (void *)d->p_probe_g[p]})
+                if (q) (void)hipIpcCloseMemHandle(q);
         }
     for (auto &e : d->ev_g) if (e) (void)hipEventDestroy(e);
+    for (auto &e : d->ev_w) if (e) (void)hipEventDestroy(e);
     if (d->ev_comm) (void)hipEventDestroy(d->ev_comm);
     if (d->comm) (void)hipStreamDestroy(d->comm);
     if (d->grad_fine) { if (h->grad == d->grad_fine) h->grad = d->grad_prev; (void)hipFree(d->grad_fine); }
-    if (d->flags) (void)hipFree(d->flags);
-    if (d->arrive) (void)hipFree(d->arrive);
+    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red})
+        if (q) (void)hipFree(q);
     if (d->err) (void)hipHostFree(d->err);
-    if (d->shm) munmap((void *)d->shm, sizeof(DpShm));
-    if (d->rank == 0 && !d->shm_name.empty()) shm_unlink(d->shm_name.c_str());
+    rdv_close(d->rdv, failed);
     delete d;
     h->dp = nullptr;
 }
@@ -1182,16 +1087,92 @@ extern "C" int bp_dp_detach(bp_handle *h)
     (void)hipStreamSynchronize(h->stream);
     bp_dp *d = h->dp;
     // nobody may unmap a buffer a peer kernel could still touch: everyone arrives here quiescent first
-    int r = d->peers_open ? dp_host_barrier(d, dp_timeout_s()) : BP_OK;
-    dp_release(h);
+    int r = BP_OK;
+    if (d->peers_open && rdv_barrier(d->rdv) != 0) r = fail(BP_ERR_STATE, g_rdv_err);
+    dp_release(h, r != BP_OK);
     return r;
 }
 
-extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
+static DpPeers dp_peers(const bp_dp *d)
+{
+    DpPeers p; memset(&p, 0, sizeof(p));
+    for (int i = 0; i < d->world; ++i) p.flags[i] = d->p_flags[i];
+    return p;
+}
+
+// Attach-time check of the memory-model contract on the group's real devices (bp_dp.h, "attach-time self-test").
+// Returns the number of mismatching words seen by THIS rank over all rounds (W direction in *bad_w, G in *bad_g).
+static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad_w, unsigned *bad_g)
+{
+    bp_dp *d = h->dp;
+    unsigned *cnt = nullptr;
+    float *sink = nullptr;
+    HIPCHK(hipHostMalloc((void **)&cnt, 2 * sizeof(unsigned), hipHostMallocMapped));
+    cnt[0] = cnt[1] = 0u;
+    HIPCHK(hipMalloc((void **)&sink, 64));
+    const DpPeers peers = dp_peers(d);
+    DpReduceArgs a; memset(&a, 0, sizeof(a));
+    for (int p = 0; p < d->world; ++p) { a.params[p] = d->p_probe_p[p]; a.grads[p] = d->p_probe_g[p]; }
+    a.world = d->world; a.rank = d->rank; a.peers = peers;
+    int rc = BP_OK;
+    for (int r = 1; r <= rounds && rc == BP_OK; ++r) {
+        const unsigned ep = ep_base + (unsigned)r;             // flag values of the probe words only ever grow (fresh flag array per attach)
+        // ---- (W): warm this device's caches with the OLD contents, let the peers overwrite, wait, re-read plainly
+        hipLaunchKernelGGL(bp_dp_probe_touch, dim3(64), dim3(256), 0, h->stream, d->probe_p, sink);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }
+        a.flag_index = bp_dp_flag_index(BP_DP_FLAG_PROBE, 0, d->rank); a.epoch = ep;
+        hipLaunchKernelGGL(bp_dp_probe_push, dim3(1), dim3(256), 0, d->comm, a, (unsigned)r);
+        hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, h->stream, d->flags, bp_dp_flag_index(BP_DP_FLAG_PROBE, 0, 0), d->world, ep,
+                           d->budget_ticks, d->err, 3u);
+        if (d->acquire_mode) hipLaunchKernelGGL(bp_dp_l2_invalidate, dim3(64), dim3(64), 0, h->stream);
+        hipLaunchKernelGGL(bp_dp_probe_check, dim3(64), dim3(256), 0, h->stream, d->probe_p, d->world, (unsigned)r, cnt);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(d->comm));
+        // ---- (G): fill the fine-grained probe with plain stores, signal behind the kernel boundary, peers read it
+        hipLaunchKernelGGL(bp_dp_probe_fill, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r, (unsigned)d->rank);
+        HIPCHK(hipEventRecord(d->ev_comm, h->stream));
+        HIPCHK(hipStreamWaitEvent(d->comm, d->ev_comm, 0));
+        hipLaunchKernelGGL(bp_dp_signal, dim3(1), dim3(64), 0, d->comm, peers, d->world, bp_dp_flag_index(BP_DP_FLAG_PROBE, 1, d->rank), ep);
+        hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, d->comm, d->flags, bp_dp_flag_index(BP_DP_FLAG_PROBE, 1, 0), d->world, ep,
+                           d->budget_ticks, d->err, 3u);
+        hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r, cnt + 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(d->comm));
+        if (*(volatile unsigned *)d->err) { rc = fail(BP_ERR_STATE, "data-parallel self-test: a peer's flag never arrived"); break; }
+        if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }    // nobody refills a probe a peer still reads
+    }
+    *bad_w = cnt[0]; *bad_g = cnt[1];
+    (void)hipHostFree(cnt); (void)hipFree(sink);
+    return rc;
+}
+
+static int dp_load_rccl(bp_dp *d)
+{
+    RcclApi &r = d->rccl;
+    r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) return fail(BP_ERR_STATE, std::string("bp_dp_attach: RCCL transport requested but librccl.so cannot be loaded: ") + dlerror());
+    *(void **)&r.GetUniqueId = dlsym(r.lib, "ncclGetUniqueId");
+    *(void **)&r.CommInitRank = dlsym(r.lib, "ncclCommInitRank");
+    *(void **)&r.ReduceScatter = dlsym(r.lib, "ncclReduceScatter");
+    *(void **)&r.AllGather = dlsym(r.lib, "ncclAllGather");
+    *(void **)&r.CommDestroy = dlsym(r.lib, "ncclCommDestroy");
+    *(void **)&r.GetErrorString = dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.ReduceScatter || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
+        return fail(BP_ERR_STATE, "bp_dp_attach: librccl.so lacks an expected symbol");
+    return BP_OK;
+}
+
+extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *key, int transport)
 {
     if (!h || !key || !*key) return fail(BP_ERR_ARG, "bp_dp_attach: null argument");
     if (world < 1 || world > BP_DP_MAXRANKS || rank < 0 || rank >= world)
         return fail(BP_ERR_ARG, "bp_dp_attach: world must be 1..8 and 0 <= rank < world");
+    if (transport != BP_DP_TRANSPORT_NATIVE && transport != BP_DP_TRANSPORT_RCCL) return fail(BP_ERR_ARG, "bp_dp_attach: unknown transport");
+    if (transport == BP_DP_TRANSPORT_RCCL && (world & (world - 1)) != 0)
+        return fail(BP_ERR_ARG, "bp_dp_attach: the RCCL transport needs a world of 1, 2, 4 or 8 (equal slices)");
     if (h->dp) return fail(BP_ERR_STATE, "bp_dp_attach: handle is already attached");
     if (h->Bg != h->B * world || h->cfg.rank_frame_offset != rank * h->B)
         return fail(BP_ERR_ARG, "bp_dp_attach: create the handle with global_bunchsize = world*bunchsize and rank_frame_offset = rank*bunchsize");
@@ -1199,15 +1180,18 @@ extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipStreamSynchronize(h->stream));
     bp_dp *d = new bp_dp();
+    memset((void *)d, 0, sizeof(*d));
     h->dp = d;
-    d->world = world; d->rank = rank; d->epoch = 0; d->peers_open = false;
+    d->world = world; d->rank = rank; d->epoch = 0; d->peers_open = false; d->backend = transport;
     d->budget_ticks = (unsigned long long)(dp_timeout_s() * 1.0e8);      // wall_clock64: 100 MHz
 #define DK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string("bp_dp_attach: ") + #x + ": " + hipGetErrorString(_e); \
-        if (d->shm) d->shm->abort_flag.store(1); dp_release(h); return fail(BP_ERR_DEVICE, m); } } while (0)
+        dp_release(h, true); return fail(BP_ERR_DEVICE, m); } } while (0)
+#define DR(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_err; dp_release(h, true); g_err = m; return _r; } } while (0)
     // the gradient buffer peers read: fine-grained (uncached in every mapping, written through by the wgrad kernels)
     // (if the runtime refuses a fine-grained allocation of this size, an ordinary one still works with the system-scope
-    // loads of bp_dp_reduce_update; the choice is local to this rank)
-    if (hipExtMallocWithFlags((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
+    // loads of bp_dp_reduce_update on ONE device; across devices the self-test below decides)
+    if (transport == BP_DP_TRANSPORT_RCCL ||      // (RCCL's kernels read it locally: ordinary cached memory)
+        hipExtMallocWithFlags((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         d->grad_fine = nullptr;
         DK(hipMalloc((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float)));
@@ -1218,6 +1202,14 @@ extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
     DK(hipMemset(d->flags, 0, BP_DP_FLAG_WORDS * sizeof(unsigned)));
     DK(hipMalloc((void **)&d->arrive, BP_MAXLAYER * sizeof(unsigned)));
     DK(hipMemset(d->arrive, 0, BP_MAXLAYER * sizeof(unsigned)));
+    DK(hipMalloc((void **)&d->probe_p, BP_DP_PROBE_FLOATS * sizeof(float)));
+    DK(hipMemset(d->probe_p, 0, BP_DP_PROBE_FLOATS * sizeof(float)));
+    if (hipExtMallocWithFlags((void **)&d->probe_g, BP_DP_PROBE_FLOATS * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        d->probe_g = nullptr;
+        DK(hipMalloc((void **)&d->probe_g, BP_DP_PROBE_FLOATS * sizeof(float)));
+    }
+    DK(hipMemset(d->probe_g, 0, BP_DP_PROBE_FLOATS * sizeof(float)));
     DK(hipHostMalloc((void **)&d->err, sizeof(unsigned), hipHostMallocMapped));
     *d->err = 0u;
     {   // the exchange yields to the GEMMs of the main stream when both have workgroups to place
@@ -1225,51 +1217,90 @@ extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key)
         DK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
         DK(hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, lo_prio));
     }
-    for (int l = 1; l < h->L; ++l) DK(hipEventCreateWithFlags(&d->ev_g[l], hipEventDisableTiming));
+    for (int l = 1; l < h->L; ++l) {
+        DK(hipEventCreateWithFlags(&d->ev_g[l], hipEventDisableTiming));
+        DK(hipEventCreateWithFlags(&d->ev_w[l], hipEventDisableTiming));
+    }
     DK(hipEventCreateWithFlags(&d->ev_comm, hipEventDisableTiming));
     DK(hipStreamSynchronize(h->stream));
+    size_t max_slice = 4;
     for (int l = 1; l < h->L; ++l) {                           // equal float4-aligned slices of [W_l|b_l]
         const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + world - 1) / world;
         const size_t a = per4 * rank < cnt4 ? per4 * rank : cnt4, b = per4 * (rank + 1) < cnt4 ? per4 * (rank + 1) : cnt4;
         d->lo[l] = h->g_off[l] + 4 * a; d->hi[l] = h->g_off[l] + 4 * b;
+        if (4 * per4 > max_slice) max_slice = 4 * per4;
+        if (transport == BP_DP_TRANSPORT_RCCL && per4 * world != cnt4) { dp_release(h, true); return fail(BP_ERR_ARG, "bp_dp_attach: RCCL transport: layer segment not divisible by the world"); }
     }
-    // ---- rendezvous
-    d->shm_name = std::string("/bpdp-") + key;
-    const int fd = shm_open(d->shm_name.c_str(), O_CREAT | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, sizeof(DpShm)) != 0) {
-        if (fd >= 0) close(fd);
-        dp_release(h);
-        return fail(BP_ERR_STATE, "bp_dp_attach: cannot create the shared rendezvous block " + std::string("/bpdp-") + key);
+    // ---- rendezvous: publish device + hipIpc handles, map every peer's
+    {
+        bp_rdv *rv = nullptr;
+        if (rdv_open(key, world, rank, dp_timeout_s(), &rv) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: " + g_rdv_err); }
+        d->rdv = rv;
     }
-    d->shm = (DpShm *)mmap(nullptr, sizeof(DpShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (d->shm == MAP_FAILED) { d->shm = nullptr; dp_release(h); return fail(BP_ERR_STATE, "bp_dp_attach: mmap of the rendezvous block failed"); }
-    DpShm *s = d->shm;
-    int w0 = 0;
-    if (!s->world.compare_exchange_strong(w0, world) && w0 != world) {
-        dp_release(h);
-        return fail(BP_ERR_ARG, "bp_dp_attach: ranks disagree on the world size (or a stale rendezvous block with this key exists)");
+    DpBlob mine; memset(&mine, 0, sizeof(mine));
+    mine.device = h->cfg.device;
+    DK(hipDeviceGetPCIBusId(mine.pci, (int)sizeof(mine.pci), h->cfg.device));
+    DK(hipIpcGetMemHandle(&mine.params, h->params));
+    DK(hipIpcGetMemHandle(&mine.grad, h->grad));
+    DK(hipIpcGetMemHandle(&mine.deltas, h->deltas));
+    DK(hipIpcGetMemHandle(&mine.flags, d->flags));
+    DK(hipIpcGetMemHandle(&mine.probe_p, d->probe_p));
+    DK(hipIpcGetMemHandle(&mine.probe_g, d->probe_g));
+    memcpy(d->rdv->shm->blob[rank], &mine, sizeof(mine));
+    if (transport == BP_DP_TRANSPORT_RCCL) {
+        DR(dp_load_rccl(d));
+        if (rank == 0) {
+            static_assert(sizeof(ncclUniqueIdBytes) <= sizeof(d->rdv->shm->shared), "unique id does not fit");
+            ncclUniqueIdBytes id;
+            const int e = d->rccl.GetUniqueId(&id);
+            if (e != 0) { dp_release(h, true); return fail(BP_ERR_DEVICE, std::string("ncclGetUniqueId: ") + d->rccl.GetErrorString(e)); }
+            memcpy(d->rdv->shm->shared, &id, sizeof(id));
+        }
     }
-    s->device[rank] = h->cfg.device; s->pid[rank] = (int)getpid();
-    DK(hipIpcGetMemHandle(&s->params[rank], h->params));
-    DK(hipIpcGetMemHandle(&s->grad[rank], h->grad));
-    DK(hipIpcGetMemHandle(&s->deltas[rank], h->deltas));
-    DK(hipIpcGetMemHandle(&s->flags[rank], d->flags));
-    int r = dp_host_barrier(d, dp_timeout_s());
-    if (r != BP_OK) { std::string m = g_err; dp_release(h); g_err = m; return r; }
+    if (rdv_barrier(d->rdv) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }
     d->peers_open = true;
     for (int p = 0; p < world; ++p) {
-        if (p == rank) { d->p_params[p] = h->params; d->p_grad[p] = h->grad; d->p_deltas[p] = h->deltas; d->p_flags[p] = d->flags; continue; }
-        DK(hipIpcOpenMemHandle((void **)&d->p_params[p], s->params[p], hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_grad[p], s->grad[p], hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_deltas[p], s->deltas[p], hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_flags[p], s->flags[p], hipIpcMemLazyEnablePeerAccess));
+        DpBlob pb; memcpy(&pb, d->rdv->shm->blob[p], sizeof(pb));
+        d->peer_device[p] = pb.device; memcpy(d->peer_pci[p], pb.pci, sizeof(pb.pci)); d->peer_pci[p][sizeof(pb.pci) - 1] = 0;
+        if (strcmp(pb.pci, mine.pci) != 0) d->distinct_devices = true;
+        if (p == rank) {
+            d->p_params[p] = h->params; d->p_grad[p] = h->grad; d->p_deltas[p] = h->deltas; d->p_flags[p] = d->flags;
+            d->p_probe_p[p] = d->probe_p; d->p_probe_g[p] = d->probe_g;
+            continue;
+        }
+        DK(hipIpcOpenMemHandle((void **)&d->p_params[p], pb.params, hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_grad[p], pb.grad, hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_deltas[p], pb.deltas, hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_flags[p], pb.flags, hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_probe_p[p], pb.probe_p, hipIpcMemLazyEnablePeerAccess));
+        DK(hipIpcOpenMemHandle((void **)&d->p_probe_g[p], pb.probe_g, hipIpcMemLazyEnablePeerAccess));
+    }
+    if (rdv_barrier(d->rdv) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }   // every rank has mapped every peer
+    if (transport == BP_DP_TRANSPORT_RCCL) {
+        ncclUniqueIdBytes id; memcpy(&id, d->rdv->shm->shared, sizeof(id));
+        const int e = d->rccl.CommInitRank(&d->rccl_comm, world, id, rank);
+        if (e != 0) { std::string m = std::string("ncclCommInitRank: ") + d->rccl.GetErrorString(e); dp_release(h, true); return fail(BP_ERR_DEVICE, m); }
+        DK(hipMalloc((void **)&d->red, (max_slice + SLACK) * sizeof(float)));
+    } else if (world > 1) {
+        // ---- the memory-model contract of the native exchange, checked on these devices before anything relies on it
+        for (int mode = 0; mode < 2; ++mode) {
+            d->acquire_mode = mode;
+            unsigned bw = 0, bg = 0;
+            DR(dp_selftest(h, 4, 4u * (unsigned)mode, &bw, &bg));
+            unsigned mine2[2] = {bw, bg}, all[2 * BP_DP_MAXRANKS];
+            if (rdv_allgather(d->rdv, mine2, sizeof(mine2), all) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }
+            unsigned tw = 0, tg = 0;
+            for (int p = 0; p < world; ++p) { tw += all[2 * p]; tg += all[2 * p + 1]; }
+            if (tg) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: self-test failed: peers read stale gradient words from a fine-grained buffer (" + std::to_string(tg) + " words)"); }
+            if (!tw) break;
+            if (mode == 1) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: self-test failed: stale weights after a peer's write-through stores even with an explicit acquire (" + std::to_string(tw) + " words)"); }
+        }
     }
 #undef DK
-    r = dp_host_barrier(d, dp_timeout_s());                    // every rank has mapped every peer
-    if (r != BP_OK) { std::string m = g_err; dp_release(h); g_err = m; return r; }
+#undef DR
     return BP_OK;
 }
+extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key) { return bp_dp_attach_ex(h, world, rank, key, BP_DP_TRANSPORT_NATIVE); }
 
 static int dp_check(bp_handle *h)
 {
@@ -1281,21 +1312,38 @@ static int dp_check(bp_handle *h)
     return BP_OK;
 }
 
-static DpPeers dp_peers(const bp_dp *d)
-{
-    DpPeers p; memset(&p, 0, sizeof(p));
-    for (int i = 0; i < d->world; ++i) p.flags[i] = d->p_flags[i];
-    return p;
-}
-
 // main stream: the weights of layer l gathered from every rank for minibatch `epoch` (none before the first)
 static hipError_t dp_wait_weights(bp_handle *h, int l, unsigned epoch)
 {
     bp_dp *d = h->dp;
     if (epoch == 0) return hipSuccess;
+    if (d->backend == BP_DP_TRANSPORT_RCCL) return hipStreamWaitEvent(h->stream, d->ev_w[l], 0);
     hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, h->stream, d->flags, bp_dp_flag_index(BP_DP_FLAG_W, l, 0), d->world, epoch,
                        d->budget_ticks, d->err, 2u);
+    if (d->acquire_mode) hipLaunchKernelGGL(bp_dp_l2_invalidate, dim3(64), dim3(64), 0, h->stream);
     return hipGetLastError();
+}
+
+static void dp_update_args(bp_handle *h, int l, DpReduceArgs &a)
+{
+    bp_dp *d = h->dp;
+    memset(&a, 0, sizeof(a));
+    a.delta = h->deltas; a.lo = d->lo[l]; a.hi = d->hi[l];
+    a.w_end = h->g_off[l] + (size_t)h->ld[l - 1] * h->ld[l];
+    a.world = d->world; a.rank = d->rank;
+    const float m = h->cfg.momentum, lr = h->cfg.lrate;
+    a.mom = m; a.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; a.wc = h->cfg.weightcost; a.ndiv = (float)h->Bg;
+    a.arrive = d->arrive + l; a.peers = dp_peers(d); a.flag_index = bp_dp_flag_index(BP_DP_FLAG_W, l, d->rank); a.epoch = d->epoch;
+}
+static int dp_update_grid(const DpReduceArgs &a)
+{
+    const size_t n4 = (a.hi - a.lo) / 4;
+    static const int max_grid = getenv("BP_DP_GRID") ? atoi(getenv("BP_DP_GRID")) : 128;   // development A/B switch
+    // few, deep workgroups: at 2048 workgroups the exchange kernel crowds the GEMMs it runs beside out of the CUs'
+    // memory pipes (C2 step through the exchange path on one GPU: 0.51 ms at 2048, 0.34 at 512, 0.28 at 128, 0.31 at 64)
+    int grid = (int)((n4 + 256 * BP_DP_UNROLL - 1) / (256 * BP_DP_UNROLL));
+    if (grid > max_grid) grid = max_grid;
+    return grid < 1 ? 1 : grid;                                // (an empty slice still raises its flag)
 }
 
 // comm stream, after the gradient segment of layer l is complete on the main stream: tell every rank, wait for
@@ -1306,25 +1354,30 @@ static hipError_t dp_exchange_layer(bp_handle *h, int l)
     hipError_t er;
     if ((er = hipEventRecord(d->ev_g[l], h->stream)) != hipSuccess) return er;
     if ((er = hipStreamWaitEvent(d->comm, d->ev_g[l], 0)) != hipSuccess) return er;
-    const DpPeers peers = dp_peers(d);
+    DpReduceArgs a;
+    dp_update_args(h, l, a);
+    if (d->backend == BP_DP_TRANSPORT_RCCL) {
+        // reduce-scatter of the segment into `red` (this rank's slice), sharded update on it, all-gather of the new W
+        // slice in place in the parameter arena; RCCL orders the ranks, the event orders the next forward of this layer
+        const size_t cnt = d->hi[l] - d->lo[l];
+        int e = d->rccl.ReduceScatter(h->grad + h->g_off[l], d->red, cnt, 7 /* ncclFloat32 */, 0 /* ncclSum */, d->rccl_comm, d->comm);
+        if (e != 0) return hipErrorUnknown;
+        a.grads[0] = d->red - a.lo;                            // the kernel indexes grads[p] + lo
+        a.params[0] = h->params;
+        a.world = 1; a.rank = 0;
+        a.peers.flags[0] = d->flags;                           // (flag raised on this rank only; nobody waits for it)
+        hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(dp_update_grid(a)), dim3(256), 0, d->comm, a);
+        if ((er = hipGetLastError()) != hipSuccess) return er;
+        e = d->rccl.AllGather(h->params + d->lo[l], h->params + h->g_off[l], cnt, 7, d->rccl_comm, d->comm);
+        if (e != 0) return hipErrorUnknown;
+        return hipEventRecord(d->ev_w[l], d->comm);
+    }
+    const DpPeers peers = a.peers;
     hipLaunchKernelGGL(bp_dp_signal, dim3(1), dim3(64), 0, d->comm, peers, d->world, bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), d->epoch);
     hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, d->comm, d->flags, bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->world, d->epoch,
                        d->budget_ticks, d->err, 1u);
-    DpReduceArgs a; memset(&a, 0, sizeof(a));
     for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
-    a.delta = h->deltas; a.lo = d->lo[l]; a.hi = d->hi[l];
-    a.w_end = h->g_off[l] + (size_t)h->ld[l - 1] * h->ld[l];
-    a.world = d->world; a.rank = d->rank;
-    const float m = h->cfg.momentum, lr = h->cfg.lrate;
-    a.mom = m; a.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; a.wc = h->cfg.weightcost; a.ndiv = (float)h->Bg;
-    a.arrive = d->arrive + l; a.peers = peers; a.flag_index = bp_dp_flag_index(BP_DP_FLAG_W, l, d->rank); a.epoch = d->epoch;
-    const size_t n4 = (a.hi - a.lo) / 4;
-    static const int max_grid = getenv("BP_DP_GRID") ? atoi(getenv("BP_DP_GRID")) : 128;   // development A/B switch
-    // few, deep workgroups: at 2048 workgroups the exchange kernel crowds the GEMMs it runs beside out of the CUs'
-    // memory pipes (C2 step through the exchange path on one GPU: 0.51 ms at 2048, 0.34 at 512, 0.28 at 128, 0.31 at 64)
-    int grid = (int)((n4 + 256 * BP_DP_UNROLL - 1) / (256 * BP_DP_UNROLL));
-    if (grid > max_grid) grid = max_grid;
-    if (grid < 1) grid = 1;                                    // (an empty slice still raises its flag)
+    const int grid = dp_update_grid(a);
     switch (d->world) {
     case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
     case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
@@ -1345,8 +1398,13 @@ static hipError_t dp_bunch(bp_handle *h, int first)
     const int L = h->L, B = h->B;
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
-    const float *x0;
-    CKE(dp_input(h, first, &x0));
+    const float *x0 = h->in + (size_t)first * h->ld[0];
+    if (use_mask(h)) {
+        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
+                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step && (first - h->mask_lo) % B == 0;
+        if (!ok) CKE(mask_range(h, first, B));
+        x0 = h->in_drop + (size_t)first * h->ld[0];
+    }
     const float *tg = h->targ + (size_t)first * h->ld[L - 1];
     const unsigned prev_epoch = d->epoch;
     d->epoch++;
@@ -1393,8 +1451,7 @@ static int dp_gather_deltas(bp_handle *h)
 {
     bp_dp *d = h->dp;
     HIPCHK(hipStreamSynchronize(h->stream));
-    int r = dp_host_barrier(d, dp_timeout_s());                // every rank quiescent: slices are final
-    if (r != BP_OK) return r;
+    if (rdv_barrier(d->rdv) != 0) return fail(BP_ERR_STATE, g_rdv_err);   // every rank quiescent: slices are final
     for (int l = 1; l < h->L; ++l) {
         const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + d->world - 1) / d->world;
         for (int p = 0; p < d->world; ++p) {
@@ -1408,7 +1465,8 @@ static int dp_gather_deltas(bp_handle *h)
         }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
-    return dp_host_barrier(d, dp_timeout_s());                 // nobody resumes training while a peer still reads
+    if (rdv_barrier(d->rdv) != 0) return fail(BP_ERR_STATE, g_rdv_err);   // nobody resumes training while a peer still reads
+    return BP_OK;
 }
 
 extern "C" int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibatches)
@@ -1418,6 +1476,27 @@ extern "C" int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibat
     if (rank) *rank = h->dp ? h->dp->rank : 0;
     if (minibatches) *minibatches = h->dp ? h->dp->epoch : 0;
     return BP_OK;
+}
+
+extern "C" int bp_dp_peer_info(bp_handle *h, int peer, int *device, char *pci_bus_id, int len, int *transport, int *acquire_mode)
+{
+    if (!h || !h->dp) return fail(BP_ERR_STATE, "bp_dp_peer_info: handle is not attached");
+    if (peer < 0 || peer >= h->dp->world) return fail(BP_ERR_ARG, "bp_dp_peer_info: peer out of range");
+    if (device) *device = h->dp->peer_device[peer];
+    if (pci_bus_id && len > 0) { strncpy(pci_bus_id, h->dp->peer_pci[peer], (size_t)len - 1); pci_bus_id[len - 1] = 0; }
+    if (transport) *transport = h->dp->backend;
+    if (acquire_mode) *acquire_mode = h->dp->acquire_mode;
+    return BP_OK;
+}
+extern "C" int bp_dp_barrier(bp_handle *h)
+{
+    if (!h || !h->dp) return fail(BP_ERR_STATE, "bp_dp_barrier: handle is not attached");
+    return rdv_barrier(h->dp->rdv) == 0 ? BP_OK : fail(BP_ERR_STATE, g_rdv_err);
+}
+extern "C" int bp_dp_allgather(bp_handle *h, const void *mine, size_t bytes, void *all)
+{
+    if (!h || !h->dp || !mine || !all) return fail(BP_ERR_STATE, "bp_dp_allgather: handle is not attached / null argument");
+    return rdv_allgather(h->dp->rdv, mine, bytes, all) == 0 ? BP_OK : fail(BP_ERR_STATE, g_rdv_err);
 }
 
 // ------------------------------------------------------------------ inference / CV

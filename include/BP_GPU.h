@@ -68,7 +68,7 @@ public:
     /* Extension: explicit configuration (every bp_config field: activation, momentum rule, dropout seed, device,
      * compute dtype, data-parallel geometry) instead of process environment, so that several trainers can coexist in one
      * process.  dp_world > 1: this object is rank dp_rank of a data-parallel group of dp_world processes (one per
-     * GPU) named dp_key; cfg.bunchsize is then the frames of a minibatch THIS rank owns and the constructor fills in
+     * GPU) named dp_key (required, unique per job on the machine); cfg.bunchsize is then the frames of a minibatch THIS rank owns and the constructor fills in
      * global_bunchsize / rank_frame_offset and joins the group (bp_dp_attach, bp_c_api.h). */
     BP_GPU(const bp_config &a_cfg, float **weights, float **bias, int dp_world = 1, int dp_rank = 0, const char *dp_key = 0)
         : handle_(0)
@@ -123,7 +123,11 @@ private:
         weightcost = cfg.weightcost; dropoutflag = cfg.dropoutflag; visible_omit = cfg.visible_omit; hid_omit = cfg.hid_omit;
         for (int i = 0; i < MAXLAYER; ++i) layersizes[i] = i < cfg.numlayers ? cfg.layersizes[i] : 0;
         check(bp_create(&cfg, weights, bias, &handle_));
-        if (dp_world > 1) check(bp_dp_attach(handle_, dp_world, dp_rank, dp_key ? dp_key : "bp"));
+        if (dp_world > 1) {
+            /* no default key: two jobs on one machine sharing a key would meet in each other's rendezvous */
+            if (!dp_key || !*dp_key) { printf("BP_GPU: a data-parallel group needs a job key (dp_key)\n"); exit(0); }
+            check(bp_dp_attach(handle_, dp_world, dp_rank, dp_key));
+        }
         printf("Created net with %d layers, bunchsize %d.\n", numlayers, bunchsize);   /* BP_GPU.cu:196 */
     }
     /* the reference reads these members afresh on every bunch (BP_GPU.cu:488-500): a caller may assign them between chunks */

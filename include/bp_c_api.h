@@ -165,46 +165,21 @@ int bp_cv_chunk_windows(bp_handle *h, const bp_window_chunk *c, float *sq_err_su
 int bp_forward_windows(bp_handle *h, const bp_window_chunk *c, float *out);         /* = bp_forward: out[n_samples][sL] (enhancement) */
 
 /* ------------------------------------------------------------------------------------
- * Data-parallel split of train_bunch_single (the reference's dead train_bunch_multi,
- * BP_GPU.cu:775-908, is the semantics donor): gradients of one local bunch are written to a
- * flat fp32 device buffer [W_1 | b_1 | W_2 | b_2 ...] (padded layout, see bp_grad_layout),
- * the caller sums that buffer over ranks (RCCL all-reduce), then bp_apply_update runs
- * kernUpdatedelta + kernAccSum (DevFunc.cu:313-318, 270-277) with n = global_bunchsize. */
-int bp_grads_resident(bp_handle *h, int first_frame);            /* one local bunch          */
-/* The same, layer by layer, so that the exchange of layer l's gradient segment can overlap the
- * backward of the layers below it: bp_dp_forward (forward + output-layer dEdX), then
- * bp_dp_backward_layer for layer = numlayers-1 ... 1 (dgrad + wgrad of that layer; afterwards
- * segment bp_grad_layout(layer) of the flat buffer is complete), then bp_apply_update_layer in
- * any order once a segment has been summed, then bp_advance_step.
- * bp_grads_resident == bp_dp_forward + every bp_dp_backward_layer;
- * bp_apply_update   == every bp_apply_update_layer + bp_advance_step. */
-int bp_dp_forward(bp_handle *h, int first_frame);
-int bp_dp_backward_layer(bp_handle *h, int layer);
-/* Finer split for a cross-step pipeline (the exchange of a step overlaps the next step's forward):
- * bp_dp_forward_layer for layer = 1 ... numlayers-1 (layer 1 names the bunch), bp_dp_dgrads (every
- * dgrad, no weight gradient yet), then bp_dp_wgrad_layer in ANY order (all dgrads are done, so the
- * largest segment can go first).  bp_dp_forward == every bp_dp_forward_layer. */
-int bp_dp_forward_layer(bp_handle *h, int first_frame, int layer);
-int bp_dp_dgrads(bp_handle *h);
-int bp_dp_wgrad_layer(bp_handle *h, int layer);
-int bp_apply_update_layer(bp_handle *h, int layer);
-int bp_advance_step(bp_handle *h);
-int bp_grad_buffer(bp_handle *h, void **device_ptr, size_t *n_floats);
-/* Adopt caller-owned device memory (e.g. a tensor the communication library already knows) as
- * the flat gradient buffer; n_floats must equal the size bp_grad_buffer reports.  The caller
- * keeps ownership and must keep it alive until bp_destroy. */
-int bp_use_grad_buffer(bp_handle *h, void *device_ptr, size_t n_floats);
+ * Gradients without the update (parity tests; no reference counterpart -- the reference never
+ * exposes layer_ydedx).  bp_grads_resident runs forward + backward of ONE local bunch starting at
+ * chunk frame first_frame with the kernels of the data-parallel step and leaves the weight and bias
+ * gradients (G_l = y_{l-1}^T . dEdX_l, BP_GPU.cu:642,647: sums over the bunch, not yet divided by n)
+ * in a flat fp32 buffer [W_1 | b_1 | W_2 | b_2 ...] of padded rows (bp_grad_layout: offset/count of
+ * layer l's segment; W_l is [pad64(prev)][pad64(cur)]); weights, momentum and the dropout stream
+ * position stay untouched.  Not valid on an attached handle. */
+int bp_grads_resident(bp_handle *h, int first_frame);
 int bp_grad_floats(bp_handle *h, size_t *n_floats);
-/* Host copies of the flat gradient buffer (synchronous): the exchange step done through host
- * memory, for callers without a device-side collective (and for parity tests). */
-int bp_read_grads(bp_handle *h, float *host_dst, size_t n_floats);
-int bp_write_grads(bp_handle *h, const float *host_src, size_t n_floats);
-int bp_apply_update(bp_handle *h);
-/* Per-layer view of the flat buffer: offset/count (floats) of layer l's [W|b] segment. */
 int bp_grad_layout(bp_handle *h, int layer, size_t *offset, size_t *count);
-/* Run the device work of this handle on an externally owned hipStream_t (passed as void*),
- * e.g. the stream a communication library orders against.  NULL restores the private stream. */
-int bp_set_stream(bp_handle *h, void *hip_stream);
+int bp_read_grads(bp_handle *h, float *host_dst, size_t n_floats);
+/* Output y_l of hidden layer `layer` (1 .. numlayers-2; layer_y, BP_GPU.h:27: post-activation, post-dropout) for the
+ * bunch processed last, [bunchsize][layersizes[layer]] floats.  Parity tests use it to count ReLU decisions that
+ * fall within fp32 rounding of zero (they depend on the GEMM's summation order).  fp32 handles only. */
+int bp_read_layer_output(bp_handle *h, int layer, float *host_dst, size_t n_floats);
 
 /* ------------------------------------------------------------------------------------
  * In-library data-parallel exchange.  One process per GPU; each rank creates its handle
@@ -221,10 +196,43 @@ int bp_set_stream(bp_handle *h, void *hip_stream);
  * calls with the same number of minibatches.  Ranks may share a device (functional testing).
  * bp_get_weights works on every rank (weights are replicated); bp_get_deltas gathers the sharded momentum
  * state and must be called by all ranks together.  A rank that stops responding makes the others fail
- * with BP_ERR_STATE after BP_DP_TIMEOUT_S seconds (default 60) instead of hanging. */
+ * with BP_ERR_STATE after BP_DP_TIMEOUT_S seconds (default 60) instead of hanging.  bp_set_hyper on an
+ * attached handle must be given the same values by every rank.
+ *
+ * Before the first step relies on it, bp_dp_attach CHECKS the memory-model contract of the exchange on the
+ * group's actual devices (peer write-through stores seen by the owner's cached loads; the owner's stores to
+ * fine-grained memory seen by peers' system-scope loads), falls back to an explicit acquire behind every wait
+ * if the first fails without one (bp_dp_peer_info reports the mode), and fails with BP_ERR_STATE otherwise.
+ *
+ * bp_dp_attach_ex selects the transport of the same sharded step: BP_DP_TRANSPORT_NATIVE (default: the peer
+ * kernels above) or BP_DP_TRANSPORT_RCCL (ncclReduceScatter of every layer's gradient segment, the sharded
+ * update, ncclAllGather of the new weights; librccl.so is loaded at run time; world 1, 2, 4 or 8; one rank
+ * per device). */
+enum { BP_DP_TRANSPORT_NATIVE = 0, BP_DP_TRANSPORT_RCCL = 1 };
 int bp_dp_attach(bp_handle *h, int world, int rank, const char *key);
+int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *key, int transport);
 int bp_dp_detach(bp_handle *h);     /* collective; also done by bp_destroy */
 int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibatches);
+/* What rank `peer` of the group attached to: HIP device ordinal in ITS process and PCI bus id ("0000:c1:00.0";
+ * buffer of >= 16 bytes), plus this group's transport and acquire mode (0 kernel boundary, 1 explicit acquire). */
+int bp_dp_peer_info(bp_handle *h, int peer, int *device, char *pci_bus_id, int len, int *transport, int *acquire_mode);
+/* Host-side barrier / all-gather of one small record (<= 64 bytes) per rank over the group's rendezvous block, for
+ * launchers that have no other channel between the ranks (bench.py: barrier around the timed region, max over ranks). */
+int bp_dp_barrier(bp_handle *h);
+int bp_dp_allgather(bp_handle *h, const void *mine, size_t bytes, void *all);
+
+/* The rendezvous underneath bp_dp_attach, usable on its own and WITHOUT a GPU (host code only): a POSIX
+ * shared-memory block "/bpdp-<key>" created by rank 0, joined by ranks 1..world-1 within timeout_s, unlinked as
+ * soon as everyone has joined (nothing is left behind by a later crash; a stale block of a crashed job with the
+ * same key is ignored and replaced).  Replaces what the reference would need an MPI/NCCL bootstrap for; the
+ * reference itself is single-process (BP_GPU.cu:29-36). */
+typedef struct bp_rdv bp_rdv;
+int bp_rdv_open(const char *key, int world, int rank, double timeout_s, bp_rdv **out);
+int bp_rdv_barrier(bp_rdv *r);
+int bp_rdv_allgather(bp_rdv *r, const void *mine, size_t bytes, void *all);   /* bytes <= 64 */
+int bp_rdv_close(bp_rdv *r);
+/* PCI bus id of a visible device (hipDeviceGetPCIBusId), for hosts that do not link the HIP runtime. */
+int bp_device_pci_bus_id(int device, char *buf, int len);
 
 /* Timing of the dominant kernels for roofline reporting: average duration (ms) of the last
  * bp_train_resident call's whole bunch loop measured with HIP events on the handle's stream. */

@@ -45,11 +45,14 @@ def main():
     kw = dict(activation=c.get("act", 0), momentum_rule=c.get("rule", 0), compute_dtype=c.get("compute_dtype", 0))
     if c.get("drop"):
         kw.update(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=99)
-    ndev = int(c.get("ndev", 1))
+    # ranks spread over every visible device (rank r on device r % ndev), so that any box with >= 2 GPUs exercises the
+    # exchange ACROSS devices; "ndev": 1 in the case pins them to one device
+    ndev = int(c.get("ndev", 0)) or dnnse_amd.device_count()
     g = dnnse_amd.BP_GPU(world, len(ls), ls, B, c.get("lr", 1.0), c.get("m", 0.5), c.get("wc", 0.0), W, b,
                          device=rank % ndev, global_bunchsize=B * world, rank_frame_offset=rank * B,
                          max_chunk_frames=max(4 * B, 64), **kw)
-    g.dp_attach(world, rank, c["key"])
+    g.dp_attach(world, rank, c["key"], transport=c.get("transport", 0))
+    peers = [g.dp_peer_info(p) for p in range(world)]
     idx = shard_rows(x.shape[0], B * world, world, rank)
     # two calls: the exchange state (epochs, flags) must carry across training calls
     half = (c["nb"] // 2) * B
@@ -61,6 +64,7 @@ def main():
     n_cv = min(x.shape[0], 3 * B + 1)
     cv = g.CrossValid(n_cv, x, t)
     out = {"cv": np.float64(cv), "epochs": np.int64(g.dp_info()[2]), "out": g.forward(x[:n_cv])}
+    json.dump({"device": rank % ndev, "ndev": ndev, "peers": peers}, open(os.path.join(outdir, "rank%d.json" % rank), "w"))
     for l in range(1, len(ls)):
         out["W%d" % l], out["b%d" % l], out["dW%d" % l], out["db%d" % l] = w[l], bb[l], dw[l], dbb[l]
     np.savez(os.path.join(outdir, "rank%d.npz" % rank), **out)

@@ -119,80 +119,59 @@ def test_dropout_mask_is_the_oracle_philox_stream(pkg, oracle_mod):
     g.close()
 
 
-def test_dp_split_equals_fused_step(pkg, oracle_mod):
-    """bp_grads_resident + bp_apply_update (the data-parallel split) == the fused single-device
-    step; and with global_bunchsize = 2*B the result equals the oracle's shard semantics."""
+def test_gradient_buffer_matches_oracle_and_fused_step(pkg, oracle_mod):
+    """bp_grads_resident (the data-parallel step's kernels: gradients stored instead of applied) against the oracle's
+    gradient itself -- a check that no ReLU flip of a later step can blur -- and against the fused step: from zero
+    momentum one fused step leaves delta = -c1 * G / n, so G is recoverable from the momentum state.  With
+    global_bunchsize = 2*B the SUM of two shards' gradients equals the oracle's gradient on the global bunch."""
     ls, B = [96, 128, 64, 20], 32
     W, b = N.glorot_net(ls, seed=9, beta=1.0)
     rng = np.random.default_rng(2)
     x = rng.normal(size=(2 * B, ls[0])).astype(np.float32)
     t = rng.normal(size=(2 * B, ls[-1])).astype(np.float32)
-    a = _mk(pkg, ls, B, W, b)
-    a.train(2 * B, x, t)
-    wa, ba = a.get_weights()
+    o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b)
     s = _mk(pkg, ls, B, W, b)
     s.upload_chunk(x, t)
     for i in range(2):
-        s.grads_resident(i * B); s.apply_update()
-    ws, bs = s.get_weights()
-    for l in range(1, len(ls)):
-        assert relerr(ws[l], wa[l]) < 1e-6 and relerr(bs[l], ba[l]) < 1e-6
-    # layer-by-layer form of the same split (what the overlapped exchange drives)
-    s2 = _mk(pkg, ls, B, W, b)
-    s2.upload_chunk(x, t)
-    for i in range(2):
-        s2.dp_forward(i * B)
-        for l in range(len(ls) - 1, 0, -1):
-            s2.dp_backward_layer(l)
+        s.grads_resident(i * B)
+        gw, gb = s.read_grads()
+        ow, ob, ys, _ = o.grads(x[i * B:(i + 1) * B], t[i * B:(i + 1) * B])
         for l in range(1, len(ls)):
-            s2.apply_update_layer(l)
-        s2.advance_step()
-    w2, b2 = s2.get_weights()
+            assert relerr(gw[l], ow[l]) < 1e-5 and relerr(gb[l], ob[l]) < 1e-5, (i, l)
+        for l in range(1, len(ls) - 1):
+            assert relerr(s.read_layer_output(l), ys[l]) < 1e-5
+    w0, b0 = s.get_weights(); d0, _ = s.get_deltas()
+    for l in range(1, len(ls)):                     # state untouched by bp_grads_resident
+        assert np.array_equal(w0[l], W[l]) and np.array_equal(b0[l], b[l]) and not d0[l].any()
+    s.grads_resident(0)
+    gw, gb = s.read_grads()
+    a = _mk(pkg, ls, B, W, b)                        # fused step from zero momentum: delta = -(1-m)*lr*G/n
+    a.train(B, x[:B], t[:B])
+    dw, dbb = a.get_deltas()
     for l in range(1, len(ls)):
-        assert np.array_equal(w2[l], ws[l]) and np.array_equal(b2[l], bs[l])
+        assert relerr(dw[l], -0.5 * gw[l] / B) < 1e-6 and relerr(dbb[l], -0.5 * gb[l] / B) < 1e-6, l
+    a.close(); s.close()
     with pytest.raises(pkg.BPError):
-        s2.dp_backward_layer(1)                     # out of order: no forward in progress
-    # cross-step pipeline order: updates of bunch i-1 interleaved with the forward of bunch i,
-    # all dgrads, then weight gradients largest (layer 1) first
-    s3 = _mk(pkg, ls, B, W, b)
-    s3.upload_chunk(x, t)
-    L = len(ls)
-    for i in range(2):
-        if i:
-            s3.advance_step()
-        for l in range(1, L):
-            if i:
-                s3.apply_update_layer(l)
-            s3.dp_forward_layer(i * B, l)
-        s3.dp_dgrads()
-        for l in range(1, L):
-            s3.dp_wgrad_layer(l)
-    for l in range(1, L):
-        s3.apply_update_layer(l)
-    s3.advance_step()
-    w3, b3 = s3.get_weights()
-    for l in range(1, L):
-        assert np.array_equal(w3[l], ws[l]) and np.array_equal(b3[l], bs[l])
-    s3.close()
-    a.close(); s.close(); s2.close()
-    # two "ranks" on one GPU: shard gradients summed on the host == oracle on the global bunch
+        s2 = _mk(pkg, ls, B, W, b)
+        try:
+            s2.upload_chunk(x[:B], t[:B])
+            s2.grads_resident(B)                      # bunch outside the resident chunk
+        finally:
+            s2.close()
+    # two "ranks" on one GPU: shard gradients summed on the host == oracle gradient on the global bunch
     Bg = 2 * B
     r0 = _mk(pkg, ls, B, W, b, global_bunchsize=Bg, rank_frame_offset=0, gpu_used=2)
     r1 = _mk(pkg, ls, B, W, b, global_bunchsize=Bg, rank_frame_offset=B, gpu_used=2)
     r0.upload_chunk(x[:B], t[:B]); r1.upload_chunk(x[B:], t[B:])
     r0.grads_resident(0); r1.grads_resident(0)
-    # sum through host memory (stand-in for the RCCL all-reduce in this 1-GPU test)
-    hs = r0.read_grads() + r1.read_grads()
-    for r in (r0, r1):
-        r.write_grads(hs)
-        r.apply_update()
-    o = oracle_mod.Oracle(ls, Bg, 1.0, 0.5, 0.0, W, b)
-    o.train(x, t)
-    for r in (r0, r1):
-        w, bb = r.get_weights()
-        for l in range(1, len(ls)):
-            assert relerr(w[l], o.W[l]) < TOL and relerr(bb[l], o.b[l]) < TOL
-        r.close()
+    (g0w, g0b), (g1w, g1b) = r0.read_grads(), r1.read_grads()
+    og = oracle_mod.Oracle(ls, Bg, 1.0, 0.5, 0.0, W, b)
+    ow, ob, _, _ = og.grads(x, t)
+    for l in range(1, len(ls)):
+        assert relerr(g0w[l] + g1w[l], ow[l]) < 1e-5 and relerr(g0b[l] + g1b[l], ob[l]) < 1e-5, l
+    with pytest.raises(pkg.BPError):
+        r0.train_resident(0, B)                       # a data-parallel handle must be attached to train
+    r0.close(); r1.close()
 
 
 def test_errors_are_reported_not_swallowed(pkg):
@@ -212,10 +191,43 @@ C2 = [257 * 11, 2048, 2048, 2048, 257]
 C3 = [257 * 12, 2048, 2048, 2048, 257]          # 11 frames + the appended noise-estimate block (NAT)
 
 
+def relu_flips(y_gpu, y_ref, y_prev, Wl, bl):
+    """Units of one hidden layer whose ReLU state differs between the device and the reference although both saw the
+    same inputs and (up to rounding) the same pre-activation.  Returns [(frame, unit, |x| of the side that is on,
+    rounding scale)], rounding scale = 2^-24 * (sum_k |y_prev[f,k] * W[k,n]| + |b[n]|): the size of one fp32 rounding
+    error of that dot product.  (Units dropped by dropout are 0 on both sides and never differ.)"""
+    fl = []
+    for f, n in zip(*np.nonzero((y_gpu > 0) != (y_ref > 0))):
+        mag = float(max(abs(y_gpu[f, n]), abs(y_ref[f, n])))
+        scale = float((np.abs(y_prev[f].astype(np.float64) * Wl[:, n].astype(np.float64)).sum() + abs(float(bl[n]))) * 2.0 ** -24)
+        fl.append((int(f), int(n), mag, scale))
+    return fl
+
+
+def backprop_rows(ls, W, ys, out, t, rows, n_scale):
+    """fp64 dEdX_l rows of the given frames from that side's OWN activations (dEdX_L = (2/n)(out - t), BP_GPU.cu:630;
+    dEdX_{l-1} = (y_{l-1} > 0) * dEdX_l . W_l^T, :611-637): what those frames contribute to every layer's gradient."""
+    L = len(ls)
+    dx = {L - 1: (2.0 / n_scale) * (out[rows].astype(np.float64) - t[rows].astype(np.float64))}
+    for l in range(L - 1, 1, -1):
+        dx[l - 1] = (ys[l - 1][rows] > 0) * (dx[l] @ W[l].astype(np.float64).T)
+    return dx
+
+
 @pytest.mark.parametrize("ls,drop", [(C2, True), (C3, False)])
 def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
-    """C2 / C3 at their real sizes (256-frame bunch): two SGD steps against the oracle."""
-    B = 256
+    """C2 / C3 at their real sizes (256-frame bunch) against the oracle at the PLAIN 1e-4 of north_star, with the one
+    effect that can legitimately break it made explicit and counted instead of being absorbed by a looser bound:
+    a hidden pre-activation that lies within fp32 rounding of zero gets its ReLU decision from the GEMM's summation
+    order, and the frame it belongs to then contributes differently to whole gradient columns.  The test (1) pins the
+    pure forward against the oracle AND against an oracle-independent torch-float64 forward, (2) takes ONE step's
+    gradient from the device (bp_grads_resident) with the hidden outputs, finds every ReLU decision that differs from
+    the oracle's, asserts that there are only a handful and that each is within a few rounding errors of zero, and then
+    asserts plain 1e-4 on the gradient with exactly those frames' contributions removed on both sides, (3) trains two
+    steps and demands plain 1e-4 on every state tensor and on the trained net's outputs whenever no decision differed;
+    when one did, the two trajectories are both correct fp32 trajectories and the bound is the fp64-accumulated one."""
+    torch = pytest.importorskip("torch")
+    B, L = 256, len(ls)
     W, b = N.glorot_net(ls, seed=1, beta=0.5)                       # the bench's init recipe
     rng = np.random.default_rng(20260927)
     x = rng.standard_normal((2 * B, ls[0]), dtype=np.float32)
@@ -224,27 +236,69 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
     g = _mk(pkg, ls, B, W, b, cap=2 * B, **kw)
     o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, **kw)                      # fp32, reference summation order
     o64 = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, acc_double=True, **kw)    # fp64 accumulation
-    assert relerr(g.forward(x[:300]), o.forward(x[:300])) < TOL                  # same weights: pure forward parity
-    g.train(2 * B, x, t)
-    assert o.train(x, t) == 2 and o64.train(x, t) == 2
+    # ---- (1) pure forward, same weights: vs the oracle and vs torch float64 (CV semantics: keep-scaled, BP_GPU.cu:703-746)
+    og = g.forward(x[:300])
+    assert relerr(og, o.forward(x[:300])) < TOL
+    h64 = torch.from_numpy(x[:300].astype(np.float64))
+    for l in range(1, L):
+        keep = (0.9 if l == 1 else 0.8) if drop else 1.0
+        h64 = keep * (h64 @ torch.from_numpy(W[l].astype(np.float64))) + torch.from_numpy(b[l].astype(np.float64))
+        if l < L - 1:
+            h64 = torch.clamp(h64, min=0.0)
+    e_t = relerr(og, h64.numpy())
+    print("pure forward vs torch float64: %.2e" % e_t)
+    assert e_t < TOL
+    # ---- (2) + (3): two training steps; before each, that bunch's gradient from the device with the ReLU decisions counted
+    g.upload_chunk(x, t)
+    flips = []
+    for i in range(2):
+        xb, tb = x[i * B:(i + 1) * B], t[i * B:(i + 1) * B]
+        Wc = [None] + [wl.copy() for wl in o.W[1:]]                  # the oracle's current weights (the device's differ by ~1e-7)
+        bc = [None] + [v.copy() for v in o.b[1:]]
+        g.grads_resident(i * B)                                      # (same dropout stream position as the step that follows)
+        gw, gb = g.read_grads()
+        ys_g = [None] + [g.read_layer_output(l) for l in range(1, L - 1)]
+        masks = [o.fill_mask(i, l, B) for l in range(L - 1)] if drop else None
+        ow, ob, ys_o, out_o = o.grads(xb, tb, masks=masks)
+        ys_g[0] = ys_o[0]                                            # (the masked input rows: same Philox stream, checked elsewhere)
+        fl = []
+        for l in range(1, L - 1):
+            fl += [(l,) + f for f in relu_flips(ys_g[l], ys_o[l], ys_g[l - 1], Wc[l], bc[l])]
+        print("bunch %d: ReLU decisions that differ from the fp32 oracle: %d of %d hidden units: %s"
+              % (i, len(fl), B * sum(ls[1:-1]), [(l, f, n, "%.1e" % m, "%.1e" % sc) for l, f, n, m, sc in fl]))
+        assert len(fl) <= 8, fl
+        for l, f, n, mag, scale in fl:
+            assert mag <= 64.0 * scale, ("a differing ReLU decision that is NOT within rounding of zero", l, f, n, mag, scale)
+        rows = sorted(set(f for _, f, _, _, _ in fl))
+        if rows:                                                     # remove exactly those frames' contributions, each side with its own states
+            out_full_g = np.zeros((B, ls[-1]))                       # the device's training-mode output of those frames, from ITS hidden outputs
+            out_full_g[rows] = ys_g[L - 2][rows].astype(np.float64) @ Wc[L - 1].astype(np.float64) + bc[L - 1].astype(np.float64)
+            dx_g = backprop_rows(ls, Wc, ys_g, out_full_g, tb, rows, B)
+            dx_o = backprop_rows(ls, Wc, ys_o, out_o, tb, rows, B)
+        for l in range(1, L):
+            Gg, Go, bg_, bo_ = gw[l].astype(np.float64), ow[l].astype(np.float64), gb[l].astype(np.float64), ob[l].astype(np.float64)
+            if rows:
+                Gg = Gg - ys_g[l - 1][rows].astype(np.float64).T @ dx_g[l]; Go = Go - ys_o[l - 1][rows].astype(np.float64).T @ dx_o[l]
+                bg_ = bg_ - dx_g[l].sum(0); bo_ = bo_ - dx_o[l].sum(0)
+            eg, eb = relerr(Gg, Go), np.abs(bg_ - bo_).max() / max(np.abs(bo_).max(), 1e-30)
+            print("  bunch %d layer %d gradient (differing frames %s removed): W %.2e  b %.2e" % (i, l, rows, eg, eb))
+            # step 0 starts from identical weights: plain 1e-4.  At step 1 a flip of step 0 has already moved the two
+            # weight sets apart (by design of the effect), so the plain bar is only owed while nothing has flipped
+            assert (eg < TOL and eb < TOL) or (i > 0 and flips), (i, l, eg, eb)
+        flips += [(i,) + f for f in fl]
+        g.train_resident(i * B, B)
+        o.train_bunch(xb, tb); o64.train_bunch(xb, tb)
     w, bb = g.get_weights()
     dw, dbb = g.get_deltas()
-
-    # (1) the contract of north_star is on OUTPUTS: the trained network's forward on fresh frames, plain 1e-4
     xf = rng.standard_normal((300, ls[0]), dtype=np.float32)
     og, o32f, o64f = g.forward(xf), o.forward(xf), o64.forward(xf)
     e_out, e_ref = relerr(og, o32f), relerr(o32f, o64f)
     print("forward output after 2 steps: rel.err vs fp32 oracle %.2e (fp32 oracle vs fp64-accumulated oracle: %.2e)" % (e_out, e_ref))
-    # plain 1e-4, or -- when a ReLU flip (see below) has pushed two correct fp32 trajectories apart by more than that --
-    # at least as close to the fp64-accumulated trajectory as the reference-order fp32 restatement is (x4)
-    assert e_out < TOL or np.abs(og.astype(np.float64) - o64f).max() <= TOL * np.abs(o64f).max() + 4.0 * np.abs(o32f.astype(np.float64) - o64f).max(), (e_out, e_ref)
-    # (2) state tensors: reported per tensor.  Plain 1e-4 where achieved; a tensor that misses it is bounded, BY NAME,
-    # against the fp64-accumulated oracle -- "as close to the exact value as the fp32 restatement of the reference is"
-    # (x4).  Why some miss: about one of the ~1.5 M hidden pre-activations per bunch lies within fp32 rounding of 0, its
-    # ReLU on/off decision then depends on the GEMM's summation order, and that one frame's contribution moves a whole
-    # column of G by ~1e-2 of max|delta| (~2e-4 of max|W|); biases start at 0 and stay ~1e-5, a sum of 256 cancelling terms.
+    diverged = len(flips) > 0 or e_ref >= TOL      # (e_ref: the oracle's own two summation orders disagree -- a flip between THEM)
+    print("differing ReLU decisions over the two steps: %d -> %s bar" % (len(flips), "fp64-bounded" if diverged else "plain 1e-4"))
+    assert e_out < TOL or (diverged and np.abs(og.astype(np.float64) - o64f).max() <= TOL * np.abs(o64f).max() + 4.0 * np.abs(o32f.astype(np.float64) - o64f).max()), (e_out, e_ref, flips)
     worst, bounded = {}, []
-    for l in range(1, len(ls)):
+    for l in range(1, L):
         for nm, a, r32, r64 in (("W", w[l], o.W[l], o64.W[l]), ("b", bb[l], o.b[l], o64.b[l]),
                                 ("dW", dw[l], o.dW[l], o64.dW[l]), ("db", dbb[l], o.db[l], o64.db[l])):
             e = relerr(a, r32)
@@ -253,6 +307,8 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
                 ea = np.abs(np.asarray(a, np.float64) - r64).max()
                 e32 = np.abs(np.asarray(r32, np.float64) - r64).max()
                 bounded.append("%s%d" % (nm, l))
+                # only legitimate when a ReLU decision differed somewhere (counted above, or between the oracle's own two orders)
+                assert diverged, ("no ReLU decision differed, yet a state tensor misses the plain bar", nm, l, e)
                 assert ea <= TOL * np.abs(r64).max() + 4.0 * e32, (nm, l, e, ea, e32)
     print("rel.err vs fp32 oracle:", {k: "%.1e" % v for k, v in worst.items()}, "| bounded against fp64 instead:", bounded)
     g.close()
@@ -283,25 +339,23 @@ def test_full_size_properties(pkg):
         assert np.array_equal(w[l], W[l]) and np.array_equal(bb[l], b[l])
         assert not dw[l].any() and not dbb[l].any()
     z.close()
-    # (c) no dropout so that the fused single-device step is the reference
+    # (c) the gradient of 2 half-bunches summed equals (to fp32 summation order) the gradient of the whole bunch:
+    # forward and dgrad are row-independent, so both runs make the same ReLU decisions
     a = _mk(pkg, ls, B, W, b, cap=B)
-    a.train(B, x, t)
-    wa, ba = a.get_weights(); a.close()
+    a.upload_chunk(x, t)
+    a.grads_resident(0)
+    gaw, gab = a.read_grads(); a.close()
     h = B // 2
     r0 = _mk(pkg, ls, h, W, b, cap=h, global_bunchsize=B, rank_frame_offset=0, gpu_used=2)
     r1 = _mk(pkg, ls, h, W, b, cap=h, global_bunchsize=B, rank_frame_offset=h, gpu_used=2)
     r0.upload_chunk(x[:h], t[:h]); r1.upload_chunk(x[h:], t[h:])
     r0.grads_resident(0); r1.grads_resident(0)
-    r0.write_grads(r0.read_grads() + r1.read_grads())
-    r0.apply_update()
-    w0, b0 = r0.get_weights()
+    (g0w, g0b), (g1w, g1b) = r0.read_grads(), r1.read_grads()
     for l in range(1, len(ls)):
-        assert relerr(w0[l], wa[l]) < 1e-5 and relerr(b0[l], ba[l]) < 1e-5
+        assert relerr(g0w[l] + g1w[l], gaw[l]) < 1e-5 and relerr(g0b[l] + g1b[l], gab[l]) < 1e-5
     r0.close(); r1.close()
 
 
-# ---------------------------------------------------------------------------------------------
-# on-device frame stacking (bp_window_chunk): bit-identical to uploading stacked rows
 def _window_case(rs, nat, n_frames=300, D=21, ctx=5, od=17, n=200):
     fea = rs.normal(size=(n_frames, D)).astype(np.float32)
     tg = rs.normal(size=(n_frames, od)).astype(np.float32)
@@ -419,46 +473,25 @@ def test_bf16_step_matches_bf16_oracle(pkg, oracle_mod, ls, B, nb, act, rule, wc
     g.close()
 
 
-def test_bf16_gradient_split_equals_fused_step(pkg):
-    """bf16 mode, data-parallel pieces on one device: bp_grads_resident + bp_apply_update (fp32 gradients in the flat
-    buffer, shadow weights refreshed by the update) == the fused bf16 step."""
+def test_bf16_gradient_buffer_equals_fused_step(pkg):
+    """bf16 mode: the gradients bp_grads_resident stores (fp32 in the flat buffer; the kernels of the data-parallel
+    step) are the ones the fused bf16 step applies: from zero momentum, delta = -c1 * G / n."""
     ls, B = [130, 192, 128, 40], 64
     W, b = N.glorot_net(ls, seed=8, beta=1.0)
     rng = np.random.default_rng(5)
-    x = rng.normal(size=(3 * B, ls[0])).astype(np.float32)
-    t = rng.normal(size=(3 * B, ls[-1])).astype(np.float32)
+    x = rng.normal(size=(B, ls[0])).astype(np.float32)
+    t = rng.normal(size=(B, ls[-1])).astype(np.float32)
     kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=3, compute_dtype=1)
     g1 = _mk(pkg, ls, B, W, b, lr=0.5, **kw)
     g2 = _mk(pkg, ls, B, W, b, lr=0.5, **kw)
-    g1.train(3 * B, x, t)
+    g1.train(B, x, t)
     g2.upload_chunk(x, t)
-    for i in range(3):
-        g2.grads_resident(i * B)
-        g2.apply_update()
-    (w1, b1), (w2, b2) = g1.get_weights(), g2.get_weights()
+    g2.grads_resident(0)
+    gw, gb = g2.read_grads()
+    dw, dbb = g1.get_deltas()
     for l in range(1, len(ls)):
-        assert relerr(w1[l], w2[l]) < 1e-6 and relerr(b1[l], b2[l]) < 1e-6
-    # the cross-step pipeline order of dp.DPPipeline (layer-by-layer calls) in bf16: same result again
-    g3 = _mk(pkg, ls, B, W, b, lr=0.5, **kw)
-    g3.upload_chunk(x, t)
-    L = len(ls)
-    for i in range(3):
-        if i:
-            g3.advance_step()
-        for l in range(1, L):
-            if i:
-                g3.apply_update_layer(l)
-            g3.dp_forward_layer(i * B, l)
-        g3.dp_dgrads()
-        for l in range(1, L):
-            g3.dp_wgrad_layer(l)
-    for l in range(1, L):
-        g3.apply_update_layer(l)
-    g3.advance_step()
-    w3, b3 = g3.get_weights()
-    for l in range(1, L):
-        assert np.array_equal(w3[l], w2[l]) and np.array_equal(b3[l], b2[l])
-    g1.close(); g2.close(); g3.close()
+        assert relerr(dw[l], -0.25 * gw[l] / B) < 1e-6 and relerr(dbb[l], -0.25 * gb[l] / B) < 1e-6, l
+    g1.close(); g2.close()
 
 
 def test_bf16_config5_shape_one_step(pkg, oracle_mod):
