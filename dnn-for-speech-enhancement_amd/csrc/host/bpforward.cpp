@@ -10,8 +10,10 @@
 //             [bunchsize=1024] [traincache=102400] [activation=relu|sigmoid] [device=0] [compute=fp32|bf16]
 //
 // out_file: an ICSI Pfile with the input's sentence structure; sentence s holds one record per window of that
-// sentence (frame id = window start + targ_offset), layersizes[last] features each.  Sentences shorter than the
-// context contribute no records (as in the reader).  Errors: message + exit(0), success: return 1 (reference convention).
+// sentence (frame id = window start + targ_offset), layersizes[last] features each: EVERY window of every sentence,
+// exactly once, in file order (chunks are cut on sentence boundaries, PfileReader::plan_inference -- the training
+// planner's cuts drop ctx-1 windows each, Interface.cc:607-614, which an enhancement tool must not).  Sentences shorter
+// than the context contribute no records (as in the reader).  Errors: message + exit(0), success: return 1 (reference convention).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -95,7 +97,7 @@ int main(int argc, char **argv)
     const std::vector<int> &fbs = reader.frames_before_sent();         // end offset (frames) of every sentence
     const int nsent = en - st + 1;
     std::vector<uint32_t> per_sent(nsent, 0);
-    const bp::PfileReader::Plan plan = reader.plan(st, en);
+    const bp::PfileReader::Plan plan = reader.plan_inference(st, en);    // every window exactly once (no training-style cut losses)
     bp::PfileReader::WindowChunk w;
     std::vector<float> out;
     std::vector<uint32_t> rec(2 + sL);

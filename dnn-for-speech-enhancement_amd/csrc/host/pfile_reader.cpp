@@ -1,5 +1,7 @@
 #include "pfile_reader.h"
 
+#include <algorithm>
+
 #include <thread>
 
 #include <stdarg.h>
@@ -118,6 +120,36 @@ PfileReader::Plan PfileReader::plan(int sent_st, int sent_en) const
     return p;
 }
 
+PfileReader::Plan PfileReader::plan_inference(int sent_st, int sent_en) const
+{
+    if (sent_en < sent_st || sent_st < 0 || sent_en >= (int)total_sents_)
+        die("sent range: %d to %d number error.", sent_st, sent_en);
+    Plan p; p.sent_st = sent_st; p.sent_en = sent_en;
+    const int ctx = cfg_.fea_context, cache = cfg_.traincache;
+    int chunk_st = sent_st == 0 ? 0 : frames_before_sent_[sent_st - 1], chunk_samples = 0, pos = chunk_st;
+    auto close_chunk = [&](int end_frame) {
+        if (end_frame > chunk_st) { p.chunk_frame_st.push_back(chunk_st); p.chunk_frame_en.push_back(end_frame); p.chunk_samples.push_back(chunk_samples); p.total_samples += (unsigned)chunk_samples; }
+        chunk_st = end_frame; chunk_samples = 0;
+    };
+    for (int s = sent_st; s <= sent_en; ++s) {
+        const int s_end = frames_before_sent_[s], len = s_end - pos;
+        int windows = len >= ctx ? len - ctx + 1 : 0;
+        if (chunk_samples + windows > cache && chunk_samples > 0) close_chunk(pos);     // this sentence starts a new chunk
+        int piece_st = pos;
+        while (windows > cache) {                          // a sentence longer than the cache: pieces overlapping by ctx-1 frames
+            chunk_st = piece_st; chunk_samples = cache;
+            close_chunk(piece_st + cache + ctx - 1);
+            piece_st += cache; windows -= cache;
+        }
+        if (piece_st != pos) chunk_st = piece_st;          // the rest of a split sentence starts the next chunk
+        chunk_samples += windows;
+        pos = s_end;
+    }
+    close_chunk(pos);
+    if (p.chunk_frame_st.empty()) { p.chunk_frame_st.push_back(chunk_st); p.chunk_frame_en.push_back(chunk_st); p.chunk_samples.push_back(0); }
+    return p;
+}
+
 void PfileReader::rand_index(int *vec, int len)
 {
     for (int i = 0; i < len - 1; ++i) {
@@ -154,7 +186,11 @@ int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowC
     const int nchunks = (int)p.chunk_frame_st.size();
     const int frame_st = p.chunk_frame_st[ci];
     int frames_need, samples;
-    if (ci == nchunks - 1) {
+    const bool inference = !p.chunk_frame_en.empty();
+    if (inference) {
+        frames_need = p.chunk_frame_en[ci] - frame_st;
+        samples = p.chunk_samples[ci];
+    } else if (ci == nchunks - 1) {
         frames_need = frames_before_sent_[p.sent_en] - frame_st;
         samples = (int)p.total_samples - cfg_.traincache * ci;
     } else {
@@ -228,6 +264,28 @@ int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowC
                     nat_id = w.n_nat();
                     w.nat.resize(w.nat.size() + (size_t)D);
                     float *nrow = &w.nat[(size_t)nat_id * D];
+                    const int sent_begin = cur_sent == 0 ? 0 : frames_before_sent_[cur_sent - 1];
+                    if (inference && cur_frame_id > sent_begin) {
+                        // a later piece of a sentence split by plan_inference: the noise estimate is still the mean of the
+                        // SENTENCE's first 6 frames, which lie before this chunk -- fetch and normalise just those
+                        const int nf = std::min(6, frames_before_sent_[cur_sent] - sent_begin);
+                        std::vector<uint32_t> head((size_t)nf * (D + 2));
+                        const long keep = ftell(fp_data_);
+                        if (fseek(fp_data_, PFILE_HEADER_SIZE + (long)sent_begin * (long)sizeof(float) * (D + 2), SEEK_SET) != 0 ||
+                            fread(head.data(), sizeof(float) * (D + 2), nf, fp_data_) != (size_t)nf)
+                            die("data pfile: cannot read the first frames of sentence %d.", cur_sent);
+                        fseek(fp_data_, keep, SEEK_SET);
+                        for (int k = 0; k < D; ++k) {
+                            float sacc = 0.0f;
+                            for (int f = 0; f < 6; ++f) {
+                                const uint32_t x = bswap(head[(size_t)(f < nf ? f : nf - 1) * (D + 2) + 2 + k]);
+                                float v; memcpy(&v, &x, 4);
+                                v -= mean_[k]; v *= dvar_[k];
+                                sacc = f == 0 ? v : sacc + v;
+                            }
+                            nrow[k] = sacc / 6.0f;
+                        }
+                    } else
                     for (int k = 0; k < D; ++k) {
                         float s = 0.0f;
                         for (int f = 0; f < 6; ++f) {

@@ -29,8 +29,19 @@ public:
     // Interface::get_pfile_info (Interface.cc:468-555): headers, sentence tables, consistency checks
     void open();
     // Interface::get_chunk_info[_cv] (Interface.cc:558-686): plan chunks over sentences [st, en] (inclusive)
-    struct Plan { std::vector<int> chunk_frame_st; int sent_st = 0, sent_en = 0; unsigned total_samples = 0; };
+    struct Plan {
+        std::vector<int> chunk_frame_st; int sent_st = 0, sent_en = 0; unsigned total_samples = 0;
+        // plan_inference only: explicit end frame and window count of every chunk (chunks may overlap by ctx-1 frames)
+        std::vector<int> chunk_frame_en, chunk_samples;
+    };
     Plan plan(int sent_st, int sent_en) const;
+    // Chunking for ENHANCEMENT (no reference counterpart: its decoder is external).  The training planner above cuts
+    // wherever the cache fills and drops the ctx-1 windows that straddle the cut (Interface.cc:607-614) -- harmless
+    // for SGD, wrong for a tool that must emit every frame.  Here chunks end on sentence boundaries; a sentence
+    // with more windows than the cache is split into pieces that overlap by ctx-1 frames.  Every window of every
+    // sentence is emitted exactly once, in file order; the noise-aware block of a later piece is still computed
+    // from the SENTENCE's first frames.
+    Plan plan_inference(int sent_st, int sent_en) const;
     // Interface::Readchunk / Readchunk_cv (Interface.cc:689-1034): returns the number of samples; rows are
     // written at a shuffled position when `shuffle` (train) else in order (CV).  in: [samples][input_dim],
     // targ: [samples][out_dim].

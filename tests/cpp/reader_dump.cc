@@ -40,6 +40,29 @@ int main(int argc, char **argv)
         fclose(o);
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "infer") && argc == 14) {
+        // reader_dump infer <fea> <norm> <fea_dim> <ctx> <targ_offset> <traincache> <input_dim> <sent_st> <sent_en> <out.bin> x x
+        //   the enhancement chunking (plan_inference): int32 nchunks, total; per chunk: int32 n, frame_st, float in[n*input_dim]
+        bp::ReaderConfig rc;
+        rc.fea_file = argv[2]; rc.targ_file = argv[2]; rc.norm_file = argv[3];
+        rc.fea_dim = atoi(argv[4]); rc.fea_context = atoi(argv[5]); rc.targ_offset = atoi(argv[6]); rc.out_dim = rc.fea_dim;
+        rc.traincache = atoi(argv[7]); rc.input_dim = atoi(argv[8]);
+        bp::PfileReader r(rc);
+        r.open();
+        const bp::PfileReader::Plan p = r.plan_inference(atoi(argv[9]), atoi(argv[10]));
+        FILE *o = fopen(argv[11], "wb");
+        const int nch = (int)p.chunk_frame_st.size(), ts = (int)p.total_samples;
+        fwrite(&nch, 4, 1, o); fwrite(&ts, 4, 1, o);
+        std::vector<float> in((size_t)rc.traincache * rc.input_dim), tg((size_t)rc.traincache * rc.out_dim);
+        for (int c = 0; c < nch; ++c) {
+            const int n = r.read_chunk(p, c, false, in.data(), tg.data());
+            if (n > rc.traincache) return 4;
+            fwrite(&n, 4, 1, o); fwrite(&p.chunk_frame_st[c], 4, 1, o);
+            fwrite(in.data(), 4, (size_t)n * rc.input_dim, o);
+        }
+        fclose(o);
+        return 0;
+    }
     if (argc > 3 && !strcmp(argv[1], "epoch")) {
         std::map<std::string, std::string> a;
         for (int i = 3; i < argc; ++i) { const char *eq = strchr(argv[i], '='); if (eq) a[std::string(argv[i], eq - argv[i])] = eq + 1; }

@@ -142,3 +142,24 @@ def read_wts(path, layersizes):
             else:
                 b.append(a)
     return W, b
+
+
+def expected_windows(fea, lens, mean_t, istd_t, ctx, nat):
+    """Every window of every sentence, in file order, with the noise-aware block from the SENTENCE's first 6 frames
+    (sequential fp32 sum / 6.0f, Interface.cc:776-779)."""
+    norm = ((fea - mean_t) * istd_t).astype(np.float32)
+    rows, o = [], 0
+    for ln in lens:
+        s = norm[o:o + ln]
+        if ln >= ctx:
+            nb = None
+            if nat:
+                acc = s[0].copy()
+                for f in range(1, 6):
+                    acc = (acc + s[min(f, ln - 1)]).astype(np.float32)
+                nb = (acc / np.float32(6.0)).astype(np.float32)
+            for j in range(ln - ctx + 1):
+                w = s[j:j + ctx].reshape(-1)
+                rows.append(np.concatenate([w, nb]) if nat else w)
+        o += ln
+    return np.stack(rows)

@@ -68,6 +68,40 @@ def test_reader_matches_restatement(tmp_path, dump_exe, D, ctx, toff, OD, cache,
     assert o == raw.size
 
 
+@pytest.mark.parametrize("D,ctx,cache,nat,lens", [
+    (6, 3, 8, True, [10, 2, 7, 25, 4, 9]),        # a sentence with 23 windows > cache 8: split with overlap, NAT from its head
+    (5, 1, 7, False, [6, 9, 3, 12, 5]),           # context 1: nothing to lose, sentences longer than the cache
+    (7, 5, 40, True, [30, 6, 41, 27, 12]),        # cuts fall on sentence boundaries only
+    (4, 2, 1000, False, [5, 6, 7]),               # one chunk
+])
+def test_inference_planner_emits_every_window_once(tmp_path, dump_exe, D, ctx, cache, nat, lens):
+    """plan_inference (enhancement, bpforward): unlike the training planner, which drops the ctx-1 windows that straddle
+    every cache cut (Interface.cc:607-614), every window of every sentence comes out exactly once and in order."""
+    rs = np.random.default_rng(5)
+    n = sum(lens)
+    fea = rs.normal(size=(n, D)).astype(np.float32) * 3 + 1
+    mean = rs.normal(size=D).astype(np.float32)
+    istd = (0.5 + rs.random(size=D)).astype(np.float32)
+    fp, npth, out = (str(tmp_path / x) for x in ("f.pfile", "n.norm", "o.bin"))
+    PU.write_pfile(fp, lens, fea); PU.write_norm(npth, mean, istd)
+    s0 = D * (ctx + 1) if nat else D * ctx
+    subprocess.check_call([dump_exe, "infer", fp, npth, str(D), str(ctx), "0", str(cache), str(s0), "0", str(len(lens) - 1), out, "x", "x"])
+    raw = np.fromfile(out, np.uint8)
+    nch, ts = np.frombuffer(raw, np.int32, 2, 0)
+    o, got = 8, []
+    for _ in range(nch):
+        cnt, _st = np.frombuffer(raw, np.int32, 2, o); o += 8
+        assert 0 <= cnt <= cache
+        got.append(np.frombuffer(raw, np.float32, cnt * s0, o).reshape(cnt, s0)); o += 4 * cnt * s0
+    assert o == raw.size
+    got = np.concatenate(got)
+    mean_t = np.array([float("%.9g" % v) for v in mean], np.float32)
+    istd_t = np.array([float("%.9g" % v) for v in istd], np.float32)
+    exp = PU.expected_windows(fea, lens, mean_t, istd_t, ctx, nat)
+    assert ts == exp.shape[0] == got.shape[0] == sum(max(0, ln - ctx + 1) for ln in lens)
+    assert np.array_equal(got, exp)
+
+
 def test_weight_file_bytes_and_roundtrip(tmp_path, dump_exe):
     ls = [6, 4, 3]
     rs = np.random.default_rng(1)
