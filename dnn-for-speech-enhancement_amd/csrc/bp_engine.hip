@@ -23,6 +23,7 @@
 #include "bp_dp.h"
 #include "bp_rdv.h"
 #include "bp_wgrad_dma.h"
+#include "bp_wgrad_dma_bf16.h"
 
 #include <dlfcn.h>
 
@@ -229,6 +230,8 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     // split over 4 workgroup rows that write partial-sum slabs; bp_out_reduce finishes the layer
     if (h->ld[L - 1] <= 512 && h->ld[L - 2] >= 1024 && h->ld[L - 2] % 256 == 0) {
         h->out_splits = 4;
+        // development A/B switch: 8 / 16 k-slices with 64x64 workgroup tiles (half the operand bytes per FLOP of the 32x32 ones)
+        if (const char *e = getenv("BP_OUT_SPLITS")) { const int v = atoi(e); if ((v == 8 || v == 16) && h->ld[L - 2] % (64 * v) == 0) h->out_splits = v; }
         h->slab_stride = Bp * h->ld[L - 1];
         CK(dev_alloc(h, &h->slabs, h->slab_stride * h->out_splits));
     }
@@ -361,9 +364,15 @@ static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const f
     if (h->out_splits > 1) {
         g.K = prev / h->out_splits; g.k_split = g.K; g.slab_stride = h->slab_stride;
         e.C = h->slabs; e.ldc = cur;
+        if (h->out_splits > 4) {
+            g.tiles_m = (M + 63) / 64; g.tiles_n = (cur + 63) / 64;
+            hipLaunchKernelGGL((bp_gemm<64, 64, 64, 2, 2, true, false, EPI_PARTIAL, 1>),
+                               dim3(g.tiles_m * g.tiles_n, h->out_splits), dim3(256), 0, st, g, e);
+        } else {
         g.tiles_m = (M + 31) / 32; g.tiles_n = (cur + 31) / 32;
         hipLaunchKernelGGL((bp_gemm<32, 32, 64, 1, 1, true, false, EPI_PARTIAL, 1>),
                            dim3(g.tiles_m * g.tiles_n, h->out_splits), dim3(256), 0, st, g, e);
+        }
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return er;
         const int n4 = M * (cur / 4);
@@ -618,6 +627,56 @@ static hipError_t bf_wgrad(bp_handle *h, int l, bool fused)
                        (float)h->Bg);
     return hipGetLastError();
 }
+// The LDS-DMA wgrad of bp_wgrad_dma_bf16.h: static bunch sizes, layers ls[0..n) in one grouped launch (bias gradient
+// fused); other bunch sizes keep bf_wgrad (GEMM kernel + bias kernel per layer).
+static bool bf_dma_ok(const bp_handle *h)
+{
+    static const bool off = getenv("BP_BF16_NO_DMA") != nullptr;                  // development A/B switch
+    return !off && (h->Bp == 128 || h->Bp == 256 || h->Bp == 512 || h->Bp == 1024);
+}
+static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
+{
+    const float m = h->cfg.momentum, lr = h->cfg.lrate;
+    const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
+    for (int i0 = 0; i0 < n; i0 += BF_WGRAD_MAXP) {
+        BfWgradMulti a; memset(&a, 0, sizeof(a));
+        const int cnt = n - i0 < BF_WGRAD_MAXP ? n - i0 : BF_WGRAD_MAXP;
+        int t = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const int l = ls[i0 + i], prev = h->ld[l - 1], cur = h->ld[l];
+            BfWgradProblem &p = a.p[i];
+            p.A = h->ybT[l - 1]; p.B = h->dxbT[l]; p.ldk = h->Bp;
+            p.tiles_m = prev / 64; p.tiles_n = cur / 64;
+            p.e = epi_zero();
+            p.e.ldc = cur; p.e.m_limit = prev; p.e.n_limit = cur; p.e.n_true = h->s[l];
+            if (fused) {
+                p.e.C = h->W[l]; p.e.aux2 = h->dW[l]; p.e.ldaux2 = cur;
+                p.e.mom = m; p.e.c1 = c1; p.e.wc = h->cfg.weightcost; p.e.ndiv = (float)h->Bg;
+                p.e.bias_w = h->b[l]; p.e.bias_d = h->db[l];
+                p.Wb = h->Wb[l]; p.ldwb = cur; p.WbT = h->WbT[l]; p.ldwbt = prev;
+            } else {
+                p.e.C = h->grad + h->g_off[l];
+                p.e.bias_g = h->grad + h->g_off[l] + (size_t)prev * cur;
+            }
+            a.first_tile[i] = t;
+            t += (p.tiles_m * p.tiles_n + 7) & ~7;             // (problem-relative block index keeps the XCD bits, see run_multi)
+        }
+        a.first_tile[cnt] = t; a.n = cnt;
+#define BF_DMA_LAUNCH(K)                                                                                             \
+        do { if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, false>), dim3(t), dim3(256), 0, h->stream, a);        \
+             else hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, true>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
+        switch (h->Bp) {
+        case 128: BF_DMA_LAUNCH(128); break;
+        case 256: BF_DMA_LAUNCH(256); break;
+        case 512: BF_DMA_LAUNCH(512); break;
+        default: BF_DMA_LAUNCH(1024); break;
+        }
+#undef BF_DMA_LAUNCH
+        hipError_t er = hipGetLastError();
+        if (er != hipSuccess) return er;
+    }
+    return hipSuccess;
+}
 static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool fused)
 {
     const int L = h->L;
@@ -626,7 +685,13 @@ static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool 
     CKE(bf_input(h, x0, h->B));
     for (int l = 1; l < L; ++l) CKE(bf_fwd(h, l, h->B, tg, nullptr, true, 1.0f));
     for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));       // every dgrad sees pre-update (shadow) weights
-    for (int l = 1; l < L; ++l) CKE(bf_wgrad(h, l, fused));
+    if (bf_dma_ok(h)) {
+        int ls[BP_MAXLAYER];
+        for (int l = 1; l < L; ++l) ls[l - 1] = l;
+        CKE(bf_wgrads_dma(h, ls, L - 1, fused));
+    } else {
+        for (int l = 1; l < L; ++l) CKE(bf_wgrad(h, l, fused));
+    }
 #undef CKE
     return hipSuccess;
 }
@@ -1416,7 +1481,7 @@ static hipError_t dp_bunch(bp_handle *h, int first)
             CKE(bf_fwd(h, l, B, tg, nullptr, true, 1.0f));
         }
         for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));
-        for (int l = 1; l < L; ++l) { CKE(bf_wgrad(h, l, false)); CKE(dp_exchange_layer(h, l)); }
+        for (int l = 1; l < L; ++l) { if (bf_dma_ok(h)) CKE(bf_wgrads_dma(h, &l, 1, false)); else CKE(bf_wgrad(h, l, false)); CKE(dp_exchange_layer(h, l)); }
     } else {
         for (int l = 1; l < L; ++l) {
             CKE(dp_wait_weights(h, l, prev_epoch));

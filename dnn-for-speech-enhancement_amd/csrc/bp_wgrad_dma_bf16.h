@@ -1,0 +1,171 @@
+// bp_wgrad_dma_bf16.h -- bf16 compute mode (BASELINE.json configs[4]): weight gradient + fused fp32 momentum update +
+// bf16 shadow refresh + bias gradient of EVERY layer in one grouped launch, LDS-DMA staged.
+//
+//   G_l = Y_{l-1}^T . dEdX_l   (SgemmNT, DevFunc.h:57-67; BP_GPU.cu:642) with bf16 operands and fp32 accumulation
+//   (v_mfma_f32_32x32x16_bf16), then kernUpdatedelta + kernAccSum (DevFunc.cu:313-318, 270-277) on the fp32 master
+//   W / delta while the tile is in registers, the refreshed bf16 copies of W in both orientations, and the bias
+//   gradient (kernAccSumrow, DevFunc.cu:224-242) by m-tile 0 from the dEdX panel it streams anyway.
+//
+// This is the structure of bp_wgrad_dma.h carried over to the bf16 operands.  Both operands are the TRANSPOSED
+// bf16 copies the producing epilogues already write (yT [unit][frame], dxT [unit][frame]): k (= frames) contiguous, so
+// a 64-row x 32-frame tile is 64 rows x 64 bytes and goes global -> LDS by `global_load_lds_dwordx4`, one 1 KiB wave
+// instruction per 16 rows.  The LDS image is lane-linear (DMA writes base + lane*16), so the bank swizzle lives in the
+// SOURCE address: 16-byte slot s of row r holds k-chunk s ^ ((r >> 2) & 3); an MFMA fragment read (ds_read_b128 of one
+// chunk per lane, 32 rows per half-wave) then touches all 64 banks once per 16-lane group.  64x64 tiles, 4 waves of
+// one 32x32 block, 32-frame k-tiles in a 4-stage ring (32 KB => 4 workgroups per CU), three tiles in flight, ONE raw
+// s_barrier per k-tile with an exact counted vmcnt; the W / delta tile is fetched by plain loads issued right behind
+// the LAST operand tile.  The step is HBM-bound here (20 bytes per parameter: fp32 W and delta read + written, two bf16
+// shadows written); what this kernel buys over bp_gemm_bf16<BEPI_WGRAD_UPDATE> is occupancy (80 VGPRs), no register
+// staging, one launch for all layers instead of one GEMM + one bias kernel per layer.
+#pragma once
+#include "bp_kernels.h"
+#include "bp_bf16.h"
+#include "bp_wgrad_dma.h"
+
+struct BfWgradProblem {
+    const bf16_t *A, *B;               // yT_{l-1} [pad64(prev)][ldk], dxT_l [pad64(cur)][ldk]; k = frame, contiguous
+    int ldk;                           // halfs per operand row (bunch rows rounded up to 64)
+    int tiles_m, tiles_n;
+    EpiArgs e;                         // fp32 side exactly as bp_wgrad_dma: C = W (or G), aux2 = delta, bias_w/d/g, mom, c1, wc, ndiv
+    bf16_t *Wb, *WbT; int ldwb, ldwbt; // refreshed shadow copies [prev][cur] / [cur][prev] (fused update only)
+};
+enum { BF_WGRAD_MAXP = 8 };
+struct BfWgradMulti { BfWgradProblem p[BF_WGRAD_MAXP]; int first_tile[BF_WGRAD_MAXP + 1]; int n; };
+
+template <int KTOT, bool STORE>
+struct WgradDmaBf {
+    static constexpr int BM = 64, BN = 64, BK = 32, ST = 4, D = ST - 1, NT = KTOT / BK;
+    static constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK, STAGE = A_STAGE + B_STAGE;     // halfs
+    static constexpr int SMEM = ST * STAGE;                                                    // halfs (32 KB)
+    static constexpr int NDMA = 2, NWD = STORE ? 0 : 32;
+    static_assert(KTOT % BK == 0 && NT > D, "bunch rows");
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    typedef const __attribute__((address_space(1))) void *glb_ptr;
+
+    static __device__ __forceinline__ void issue_tile(const BfWgradProblem &g, int m0, int n0, int k0, bf16_t *smem, int st, int wave, int lane)
+    {
+        const int r = wave * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);            // LDS slot lane&3 of row r <- k-chunk c
+        __builtin_amdgcn_global_load_lds((glb_ptr)(g.A + (size_t)(m0 + r) * g.ldk + k0 + c * 8), (lds_ptr)(smem + st * STAGE + wave * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(g.B + (size_t)(n0 + r) * g.ldk + k0 + c * 8), (lds_ptr)(smem + st * STAGE + A_STAGE + wave * 512), 16, 0, 0);
+    }
+    static __device__ __forceinline__ void multiply(const bf16_t *smem, int st, int ra, int rb, int kh, f32x16 &acc)
+    {
+        const bf16_t *ap = smem + st * STAGE + ra * BK, *bp = smem + st * STAGE + A_STAGE + rb * BK;
+        const int sa = (ra >> 2) & 3, sb = (rb >> 2) & 3;
+        bf16x8_t a[2], b[2];
+        // keep the fragment reads and their MFMAs inside this k-tile's barrier interval: the stage is refilled by DMA
+        // right after the NEXT barrier, so every read of it must have completed (been consumed) before that barrier
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a[q] = *reinterpret_cast<const bf16x8_t *>(ap + (((2 * q + kh) ^ sa) * 8));
+            b[q] = *reinterpret_cast<const bf16x8_t *>(bp + (((2 * q + kh) ^ sb) * 8));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], b[q], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int T>
+    static __device__ __forceinline__ void iter(const BfWgradProblem &g, int m0, int n0, bf16_t *smem, int wave, int lane, int tid, int ra, int rb,
+                                                int kh, int mb, int nb, bool do_bias, float &bsum, f32x16 &acc, EpiPre &pre)
+    {
+        if constexpr (T < NT) {
+            // in flight here: tiles T .. min(T+D, NT)-1, plus the 32 W/delta loads once the last tile has been issued
+            constexpr int tiles_after = (T + D < NT ? D : NT - T) - 1;
+            constexpr bool wd_out = T + D > NT;
+            VmWait<tiles_after * NDMA + (wd_out ? NWD : 0)>::go();
+            __builtin_amdgcn_s_barrier();
+            if constexpr (T + D < NT) issue_tile(g, m0, n0, (T + D) * BK, smem, (T + D) % ST, wave, lane);
+            if constexpr (T + D == NT && !STORE) epilogue_fetch<EPI_WGRAD_UPDATE, 0, 16>(g.e, mb, nb, lane, pre);     // behind the last tile
+            if (do_bias) {          // column sums of dEdX: row (tid >> 2) of the B tile, one 16-byte chunk per thread (any slot order)
+                // (inline asm: for a plain LDS load next to in-flight LDS-DMA hipcc drains vmcnt(0) first, which would
+                // serialise this workgroup's whole ring; the counted wait above already covers the stage read here)
+                uint4 u;
+                const unsigned la = (unsigned)(uintptr_t)(lds_ptr)(smem + (T % ST) * STAGE + A_STAGE + (tid >> 2) * BK + (tid & 3) * 8);
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(u) : "v"(la) : "memory");
+                const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bsum += __uint_as_float(w4[j] << 16); bsum += __uint_as_float(w4[j] & 0xFFFF0000u); }
+            }
+            multiply(smem, T % ST, ra, rb, kh, acc);
+            iter<T + 1>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, mb, nb, do_bias, bsum, acc, pre);
+        }
+    }
+    static __device__ __forceinline__ void run(const BfWgradProblem &g, int first_block, int stride, bf16_t *smem)
+    {
+        const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wm = wave >> 1, wn = wave & 1;
+        const EpiArgs &e = g.e;
+        for (int b = first_block; b < g.tiles_m * g.tiles_n; b += stride) {
+            int tile_m, tile_n;
+            if ((g.tiles_n & 7) == 0) { const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3; tile_n = xcd * per + j % per; tile_m = j / per; }
+            else { tile_m = b % g.tiles_m; tile_n = b / g.tiles_m; }
+            const int m0 = tile_m * BM, n0 = tile_n * BN, mb = m0 + wm * 32, nb = n0 + wn * 32;
+            const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31), kh = lane >> 5;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const bool do_bias = tile_m == 0;
+            float bsum = 0.f;
+            EpiPre pre;
+#pragma unroll
+            for (int t = 0; t < D; ++t) issue_tile(g, m0, n0, t * BK, smem, t, wave, lane);
+            iter<0>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, mb, nb, do_bias, bsum, acc, pre);
+            if (do_bias) {
+                bsum += __shfl_xor(bsum, 1);
+                bsum += __shfl_xor(bsum, 2);
+                const int n = n0 + (tid >> 2);
+                if ((tid & 3) == 0 && n < e.n_limit) {
+                    if constexpr (STORE) {
+                        e.bias_g[n] = bsum;
+                    } else {
+                        const float d = e.mom * e.bias_d[n] - e.c1 * (bsum / e.ndiv + 0.0f * e.bias_w[n]);
+                        e.bias_d[n] = d;
+                        e.bias_w[n] = d + 1.0f * e.bias_w[n];
+                    }
+                }
+            }
+            // ---- epilogue: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block.
+            // Padded rows / columns hold zeros in W, delta and G and stay zero under the update: no predicates.
+            const int n = nb + (lane & 31), rbase = mb + 4 * (lane >> 5);
+            if constexpr (STORE) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n] = acc[r];
+            } else {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const size_t i = (size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n;
+                    const float w = pre.p0[r];
+                    const float d = e.mom * pre.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);     // kernUpdatedelta
+                    e.aux2[i] = d;
+                    v[r] = d + 1.0f * w;                                                         // kernAccSum
+                    e.C[i] = v[r];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16_t hb[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        hb[j] = f2bf(v[4 * q + j]);
+                        g.Wb[(size_t)(rbase + 8 * q + j) * g.ldwb + n] = hb[j];
+                    }
+                    const uint2 pk = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+                    *reinterpret_cast<uint2 *>(g.WbT + (size_t)n * g.ldwbt + rbase + 8 * q) = pk;
+                }
+            }
+            if (b + stride < g.tiles_m * g.tiles_n) __syncthreads();      // the ring is refilled by the next tile's prologue
+        }
+    }
+};
+
+template <int KTOT, bool STORE>
+__global__ __launch_bounds__(256, 4) void bp_wgrad_dma_bf16(const BfWgradMulti a)
+{
+    using K = WgradDmaBf<KTOT, STORE>;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[K::SMEM];
+    const int b = blockIdx.x;
+    int p = 0;
+    while (p + 1 < a.n && b >= a.first_tile[p + 1]) ++p;
+    K::run(a.p[p], b - a.first_tile[p], a.first_tile[p + 1] - a.first_tile[p], smem);
+}

@@ -27,6 +27,7 @@ CASES = [
     ("c4_8x256", [2827, 2048, 2048, 2048, 257], 256, 8, 2, {"beta": 0.5}),           # configs[3], real shape
     ("c2_world1", [2827, 2048, 257], 256, 1, 2, {"drop": True}),                     # exchange path with a single rank
     ("bf16_2", [300, 256, 128, 64], 64, 2, 2, {"compute_dtype": 1, "lr": 0.5}),
+    ("bf16_dma_2", [300, 256, 128, 64], 128, 2, 2, {"compute_dtype": 1, "lr": 0.5, "drop": True}),   # bunch 128: the LDS-DMA gradient-store kernel
 ]
 
 

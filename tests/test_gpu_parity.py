@@ -439,6 +439,7 @@ BF_CASES = [
     ([70, 128, 64, 20], 64, 2, 1, 1, 0.001, False),               # Sigmoid, classic momentum, weight cost
     ([257, 320, 192, 129], 96, 2, 0, 0, 0.0, True),               # dropout, ragged bunch
     ([300, 1024, 1024, 257], 256, 2, 0, 0, 0.0, True),            # several k-tiles and workgroups per GEMM
+    ([70, 130, 64, 20], 128, 2, 1, 1, 0.001, True),               # LDS-DMA wgrad (bunch 128): odd widths, Sigmoid, classic, weight cost
 ]
 
 
