@@ -66,6 +66,29 @@ __global__ void bp_dp_wait(const unsigned *flags, int base, int world, unsigned 
     }
 }
 
+// The same two kernels for SEVERAL flag words at once (the layers of one grouped weight-gradient launch).
+struct DpIdx { int n; int index[16]; };
+__global__ void bp_dp_signal_n(DpPeers peers, int world, DpIdx idx, unsigned epoch)
+{
+    const int p = threadIdx.x;
+    if (p < world)
+        for (int i = 0; i < idx.n; ++i) __hip_atomic_store(peers.flags[p] + idx.index[i], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void bp_dp_wait_n(const unsigned *flags, DpIdx bases, int world, unsigned epoch, unsigned long long budget_ticks, unsigned *err, unsigned code)
+{
+    const int p = threadIdx.x;
+    if (p < world) {
+        const unsigned long long t0 = wall_clock64();
+        for (int i = 0; i < bases.n; ++i)
+            for (;;) {
+                const unsigned v = __hip_atomic_load(flags + bases.index[i] + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((int)(v - epoch) >= 0) break;
+                if (wall_clock64() - t0 > budget_ticks) { atomicExch(err, code * 1000u + (unsigned)p + 1u); return; }
+                __builtin_amdgcn_s_sleep(16);
+            }
+    }
+}
+
 struct DpReduceArgs {
     const float *grads[BP_DP_MAXRANKS];   // every rank's flat gradient buffer (own entry = local pointer)
     float *params[BP_DP_MAXRANKS];        // every rank's flat parameter arena

@@ -230,8 +230,8 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     // split over 4 workgroup rows that write partial-sum slabs; bp_out_reduce finishes the layer
     if (h->ld[L - 1] <= 512 && h->ld[L - 2] >= 1024 && h->ld[L - 2] % 256 == 0) {
         h->out_splits = 4;
-        // development A/B switch: 8 / 16 k-slices with 64x64 workgroup tiles (half the operand bytes per FLOP of the 32x32 ones)
-        if (const char *e = getenv("BP_OUT_SPLITS")) { const int v = atoi(e); if ((v == 8 || v == 16) && h->ld[L - 2] % (64 * v) == 0) h->out_splits = v; }
+        // (measured round 3: 8 / 16 k-slices with 64x64 workgroup tiles -- half the operand bytes per FLOP -- are no faster:
+        // C2 step 0.2216 ms with 4 slices, 0.2204 with 8, 0.2237 with 16; the layer is launch/latency-bound)
         h->slab_stride = Bp * h->ld[L - 1];
         CK(dev_alloc(h, &h->slabs, h->slab_stride * h->out_splits));
     }
@@ -364,15 +364,9 @@ static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const f
     if (h->out_splits > 1) {
         g.K = prev / h->out_splits; g.k_split = g.K; g.slab_stride = h->slab_stride;
         e.C = h->slabs; e.ldc = cur;
-        if (h->out_splits > 4) {
-            g.tiles_m = (M + 63) / 64; g.tiles_n = (cur + 63) / 64;
-            hipLaunchKernelGGL((bp_gemm<64, 64, 64, 2, 2, true, false, EPI_PARTIAL, 1>),
-                               dim3(g.tiles_m * g.tiles_n, h->out_splits), dim3(256), 0, st, g, e);
-        } else {
         g.tiles_m = (M + 31) / 32; g.tiles_n = (cur + 31) / 32;
         hipLaunchKernelGGL((bp_gemm<32, 32, 64, 1, 1, true, false, EPI_PARTIAL, 1>),
                            dim3(g.tiles_m * g.tiles_n, h->out_splits), dim3(256), 0, st, g, e);
-        }
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return er;
         const int n4 = M * (cur / 4);
@@ -1411,46 +1405,55 @@ static int dp_update_grid(const DpReduceArgs &a)
     return grid < 1 ? 1 : grid;                                // (an empty slice still raises its flag)
 }
 
-// comm stream, after the gradient segment of layer l is complete on the main stream: tell every rank, wait for
-// every rank's segment, then reduce this rank's slice, update it and write the new weights to every rank
-static hipError_t dp_exchange_layer(bp_handle *h, int l)
+// comm stream, after the gradient segments of layers ls[0..n) are complete on the main stream (ONE event: every event
+// record costs the main stream a ~6 us bubble, profiles/r03_dp_world1_timeline.txt): tell every rank, wait for every
+// rank's segments, then per layer reduce this rank's slice, update it and write the new weights to every rank
+static hipError_t dp_exchange_layers(bp_handle *h, const int *ls, int n)
 {
     bp_dp *d = h->dp;
     hipError_t er;
-    if ((er = hipEventRecord(d->ev_g[l], h->stream)) != hipSuccess) return er;
-    if ((er = hipStreamWaitEvent(d->comm, d->ev_g[l], 0)) != hipSuccess) return er;
-    DpReduceArgs a;
-    dp_update_args(h, l, a);
-    if (d->backend == BP_DP_TRANSPORT_RCCL) {
-        // reduce-scatter of the segment into `red` (this rank's slice), sharded update on it, all-gather of the new W
-        // slice in place in the parameter arena; RCCL orders the ranks, the event orders the next forward of this layer
-        const size_t cnt = d->hi[l] - d->lo[l];
-        int e = d->rccl.ReduceScatter(h->grad + h->g_off[l], d->red, cnt, 7 /* ncclFloat32 */, 0 /* ncclSum */, d->rccl_comm, d->comm);
-        if (e != 0) return hipErrorUnknown;
-        a.grads[0] = d->red - a.lo;                            // the kernel indexes grads[p] + lo
-        a.params[0] = h->params;
-        a.world = 1; a.rank = 0;
-        a.peers.flags[0] = d->flags;                           // (flag raised on this rank only; nobody waits for it)
-        hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(dp_update_grid(a)), dim3(256), 0, d->comm, a);
+    if ((er = hipEventRecord(d->ev_g[ls[0]], h->stream)) != hipSuccess) return er;
+    if ((er = hipStreamWaitEvent(d->comm, d->ev_g[ls[0]], 0)) != hipSuccess) return er;
+    if (d->backend != BP_DP_TRANSPORT_RCCL) {
+        const DpPeers peers = dp_peers(d);
+        DpIdx sig, wt; sig.n = wt.n = n;
+        for (int i = 0; i < n; ++i) { sig.index[i] = bp_dp_flag_index(BP_DP_FLAG_GRAD, ls[i], d->rank); wt.index[i] = bp_dp_flag_index(BP_DP_FLAG_GRAD, ls[i], 0); }
+        hipLaunchKernelGGL(bp_dp_signal_n, dim3(1), dim3(64), 0, d->comm, peers, d->world, sig, d->epoch);
+        hipLaunchKernelGGL(bp_dp_wait_n, dim3(1), dim3(64), 0, d->comm, d->flags, wt, d->world, d->epoch, d->budget_ticks, d->err, 1u);
+    }
+    for (int i = 0; i < n; ++i) {
+        const int l = ls[i];
+        DpReduceArgs a;
+        dp_update_args(h, l, a);
+        if (d->backend == BP_DP_TRANSPORT_RCCL) {
+            // reduce-scatter of the segment into `red` (this rank's slice), sharded update on it, all-gather of the new W
+            // slice in place in the parameter arena; RCCL orders the ranks, the event orders the next forward of this layer
+            const size_t cnt = d->hi[l] - d->lo[l];
+            int e = d->rccl.ReduceScatter(h->grad + h->g_off[l], d->red, cnt, 7 /* ncclFloat32 */, 0 /* ncclSum */, d->rccl_comm, d->comm);
+            if (e != 0) return hipErrorUnknown;
+            a.grads[0] = d->red - a.lo;                            // the kernel indexes grads[p] + lo
+            a.params[0] = h->params;
+            a.world = 1; a.rank = 0;
+            a.peers.flags[0] = d->flags;                           // (flag raised on this rank only; nobody waits for it)
+            hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(dp_update_grid(a)), dim3(256), 0, d->comm, a);
+            if ((er = hipGetLastError()) != hipSuccess) return er;
+            e = d->rccl.AllGather(h->params + d->lo[l], h->params + h->g_off[l], cnt, 7, d->rccl_comm, d->comm);
+            if (e != 0) return hipErrorUnknown;
+            if ((er = hipEventRecord(d->ev_w[l], d->comm)) != hipSuccess) return er;
+            continue;
+        }
+        for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
+        const int grid = dp_update_grid(a);
+        switch (d->world) {
+        case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
+        case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
+        case 4: hipLaunchKernelGGL(bp_dp_reduce_update<4>, dim3(grid), dim3(256), 0, d->comm, a); break;
+        case 8: hipLaunchKernelGGL(bp_dp_reduce_update<8>, dim3(grid), dim3(256), 0, d->comm, a); break;
+        default: hipLaunchKernelGGL(bp_dp_reduce_update<0>, dim3(grid), dim3(256), 0, d->comm, a); break;
+        }
         if ((er = hipGetLastError()) != hipSuccess) return er;
-        e = d->rccl.AllGather(h->params + d->lo[l], h->params + h->g_off[l], cnt, 7, d->rccl_comm, d->comm);
-        if (e != 0) return hipErrorUnknown;
-        return hipEventRecord(d->ev_w[l], d->comm);
     }
-    const DpPeers peers = a.peers;
-    hipLaunchKernelGGL(bp_dp_signal, dim3(1), dim3(64), 0, d->comm, peers, d->world, bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), d->epoch);
-    hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, d->comm, d->flags, bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->world, d->epoch,
-                       d->budget_ticks, d->err, 1u);
-    for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
-    const int grid = dp_update_grid(a);
-    switch (d->world) {
-    case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    case 4: hipLaunchKernelGGL(bp_dp_reduce_update<4>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    case 8: hipLaunchKernelGGL(bp_dp_reduce_update<8>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    default: hipLaunchKernelGGL(bp_dp_reduce_update<0>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    }
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 // One data-parallel minibatch (this rank's shard starts at chunk frame `first`).  Per layer: wait for the gathered
@@ -1481,16 +1484,33 @@ static hipError_t dp_bunch(bp_handle *h, int first)
             CKE(bf_fwd(h, l, B, tg, nullptr, true, 1.0f));
         }
         for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));
-        for (int l = 1; l < L; ++l) { if (bf_dma_ok(h)) CKE(bf_wgrads_dma(h, &l, 1, false)); else CKE(bf_wgrad(h, l, false)); CKE(dp_exchange_layer(h, l)); }
+        // layer 1 (the largest segment, needed first by the next forward) goes out alone; the rest as one group: its
+        // exchange queues behind layer 1's on the comm stream anyway, and one launch + one event replace L-2 of each
+        int rest[BP_MAXLAYER], nrest = 0;
+        for (int l = 2; l < L; ++l) rest[nrest++] = l;
+        const int one = 1;
+        if (bf_dma_ok(h)) {
+            CKE(bf_wgrads_dma(h, &one, 1, false)); CKE(dp_exchange_layers(h, &one, 1));
+            if (nrest) { CKE(bf_wgrads_dma(h, rest, nrest, false)); CKE(dp_exchange_layers(h, rest, nrest)); }
+        } else {
+            for (int l = 1; l < L; ++l) { CKE(bf_wgrad(h, l, false)); CKE(dp_exchange_layers(h, &l, 1)); }
+        }
     } else {
         for (int l = 1; l < L; ++l) {
             CKE(dp_wait_weights(h, l, prev_epoch));
             CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
         }
         for (int l = L - 1; l >= 2; --l) CKE(launch_dgrad(h, h->stream, l, B));
-        for (int l = 1; l < L; ++l) {
-            CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], false));
-            CKE(dp_exchange_layer(h, l));
+        // layer 1 (the largest segment, needed first by the next forward) goes out alone; the rest as ONE grouped launch:
+        // its exchange queues behind layer 1's on the comm stream anyway, and one launch + one event replace L-2 of each
+        Prepared ws[BP_MAXLAYER]; int rest[BP_MAXLAYER], nrest = 0;
+        const int one = 1;
+        CKE(launch_wgrad(h, h->stream, 1, B, x0, false));
+        CKE(dp_exchange_layers(h, &one, 1));
+        for (int l = 2; l < L; ++l) { ws[nrest] = prep_wgrad(h, l, B, h->y[l - 1], false); rest[nrest++] = l; }
+        if (nrest) {
+            CKE(run_wgrads(h->stream, ws, nrest, true));
+            CKE(dp_exchange_layers(h, rest, nrest));
         }
     }
 #undef CKE
@@ -1749,16 +1769,16 @@ __global__ __launch_bounds__(256) void bp_peak_mfma_f32(float *sink, int iters, 
     for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
     if (s == 1.2345e-30f) sink[threadIdx.x] = s;
 }
+// One float4 per thread, no loop, the whole 1 GiB in one grid (tools/copy_probe.hip: 6.27 TB/s plain, 6.59 TB/s with
+// nontemporal accesses on these boxes; the grid-stride form with 4 loads in flight that stood here before reached 4.5-4.8).
+template <bool NT>
 __global__ __launch_bounds__(256) void bp_peak_copy(float4 *dst, const float4 *src, size_t n4)
 {
-    // 4 independent 16-byte loads in flight per lane, then 4 stores; consecutive lanes touch consecutive 16-byte words
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n4; i += stride) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f4v *>(src) + i), reinterpret_cast<f4v *>(dst) + i);
+    else dst[i] = src[i];
 }
 extern "C" int bp_measure_peaks(bp_handle *h, float *mfma_f32_tflops, float *hbm_copy_gbs)
 {
@@ -1786,9 +1806,10 @@ extern "C" int bp_measure_peaks(bp_handle *h, float *mfma_f32_tflops, float *hbm
     HIPCHK(hipMalloc((void **)&src, bytes)); HIPCHK(hipMalloc((void **)&dst, bytes));
     HIPCHK(hipMemsetAsync(src, 1, bytes, h->stream));
     best = 0.f;
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < 6; ++rep) {
         HIPCHK(hipEventRecord(a, h->stream));
-        hipLaunchKernelGGL(bp_peak_copy, dim3(256 * (rep < 2 ? 8 : 32)), dim3(256), 0, h->stream, dst, src, bytes / 16);   // two grid sizes, best reported
+        if (rep < 3) hipLaunchKernelGGL(bp_peak_copy<false>, dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, h->stream, dst, src, bytes / 16);
+        else hipLaunchKernelGGL(bp_peak_copy<true>, dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, h->stream, dst, src, bytes / 16);   // plain and nontemporal, best reported
         HIPCHK(hipEventRecord(b, h->stream));
         HIPCHK(hipEventSynchronize(b));
         HIPCHK(hipEventElapsedTime(&ms, a, b));

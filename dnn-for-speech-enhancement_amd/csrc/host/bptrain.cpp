@@ -9,7 +9,10 @@
 // the process forks N ranks, one per GPU (rank r on device r % visible devices); `bunchsize` is the GLOBAL minibatch as
 // in the reference's per-GPU split (BP_GPU.cu:29-36), every rank trains on its bunchsize/N frames of each minibatch and
 // the library exchanges gradients / weights itself (bp_dp_attach, include/bp_c_api.h).  Rank 0 writes the log, the
-// weights file and runs the cross-validation.
+// weights file and runs the cross-validation.  ONE reader per node, as in the reference (one Interface feeding all
+// devices, Interface.cc:689-861, BP_GPU.cu:269-277): the ranks share a two-slot chunk ring in shared memory
+// (chunk_ring.h); rank 0 plans and shuffles, every rank converts 1/N of each chunk's frames, every Pfile byte is read
+// once per node, and each rank uploads the raw frames plus only ITS rows' index tables.
 //
 // Extra optional keys (defaults = live reference behaviour): activation=relu|sigmoid,
 // momentum_rule=live|classic, seed=<u64> (dropout stream), device=<ordinal>, compute=fp32|bf16;
@@ -29,8 +32,11 @@
 #include <vector>
 
 #include "../../../include/BP_GPU.h"
+#include "chunk_ring.h"
 #include "pfile_reader.h"
 #include "wts_io.h"
+
+#include <thread>
 
 struct Params {
     std::string fea_file, norm_file, targ_file, outwts_file, log_file, initwts_file, train_range, cv_range;
@@ -43,16 +49,7 @@ struct Params {
     unsigned long long dropout_seed = 0;
 };
 
-// Rows of a chunk that rank `rank` of `world` trains on: its B = Bg/world frames of every full global minibatch
-// (rows i*Bg + rank*B ... of minibatch i; the partial last minibatch is dropped as in BP_GPU.cu:315-318).
-static std::vector<int> shard_rows(int n_samples, int global_bunch, int world, int rank)
-{
-    const int B = global_bunch / world, nb = n_samples / global_bunch;
-    std::vector<int> idx((size_t)nb * B);
-    for (int i = 0; i < nb; ++i)
-        for (int j = 0; j < B; ++j) idx[(size_t)i * B + j] = i * global_bunch + rank * B + j;
-    return idx;
-}
+using bp::shard_rows;
 
 typedef bp::PfileReader::WindowChunk WindowChunk;
 static bp_window_chunk describe(const WindowChunk &w, int context)
@@ -141,29 +138,22 @@ int main(int argc, char **argv)
         else if (k == "prefetch") P.prefetch = atoi(v.c_str()) != 0;
         // unknown names are silently ignored, as in the reference (e.g. the .pl passes numlayers=)
     }
-    // ---- gpu_used > 1: fork the data-parallel ranks before anything touches files or the GPU
+    // ---- gpu_used > 1: data-parallel ranks, forked further down -- after the parent has opened the files, initialised the
+    // weights, planned and shuffled the chunks and mapped the shared chunk ring (all inherited), but before anything
+    // touches the GPU
     const int world = P.gpu_used > 1 ? P.gpu_used : 1;
     int rank = 0;
     std::vector<pid_t> kids;
     const std::string dp_key = "bptrain-" + std::to_string((long)getpid());
-    if (world > 1) {
-        if (world > 8 || P.bunchsize % world != 0) {
-            printf("gpu_used=%d: needs 2..8 GPUs and a bunchsize that is a multiple of it\n", world);
-            exit(0);
-        }
-        fflush(stdout);
-        for (int r = 1; r < world; ++r) {
-            const pid_t c = fork();
-            if (c < 0) { printf("fork failed\n"); exit(0); }
-            if (c == 0) { rank = r; kids.clear(); break; }
-            kids.push_back(c);
-        }
+    if (world > 1 && (world > 8 || P.bunchsize % world != 0)) {
+        printf("gpu_used=%d: needs 2..8 GPUs and a bunchsize that is a multiple of it\n", world);
+        exit(0);
     }
-    const bool lead = rank == 0;
-    FILE *log = fopen(lead ? P.log_file.c_str() : "/dev/null", "wt");
+    bool lead = true;
+    FILE *log = fopen(P.log_file.c_str(), "wt");
     if (!log) { printf("can not open output log file: %s\n", P.log_file.c_str()); exit(0); }
-    FILE *fp_out = lead ? fopen(P.outwts_file.c_str(), "wb") : nullptr;
-    if (lead && !fp_out) { fprintf(log, "can not open output weights file: %s\n", P.outwts_file.c_str()); exit(0); }
+    FILE *fp_out = fopen(P.outwts_file.c_str(), "wb");
+    if (!fp_out) { fprintf(log, "can not open output weights file: %s\n", P.outwts_file.c_str()); exit(0); }
     const int L = P.numlayers;
     if (L < 2 || L > MAXLAYER - 1) { fprintf(log, "layersizes: need 2..%d layer sizes\n", MAXLAYER - 1); exit(0); }
     // parameter echo (Interface.cc:267-298)
@@ -233,25 +223,6 @@ int main(int argc, char **argv)
         indata.resize((size_t)P.layersizes[0] * P.traincache); targ.resize((size_t)P.layersizes[L - 1] * P.traincache);
     }
 
-    // ---- BPtrain.cc:31-96
-    bp_config cfg;
-    memset(&cfg, 0, sizeof(cfg));
-    cfg.gpu_used = P.gpu_used > 0 ? P.gpu_used : 1; cfg.numlayers = L;
-    for (int i = 0; i < L; ++i) cfg.layersizes[i] = P.layersizes[i];
-    cfg.bunchsize = P.bunchsize / world;                    // BP_GPU.cu:29-36: the bunch is split over the GPUs
-    cfg.lrate = P.lrate; cfg.momentum = P.momentum; cfg.weightcost = P.weightcost;
-    cfg.dropoutflag = P.dropoutflag; cfg.visible_omit = P.visible_omit; cfg.hid_omit = P.hid_omit;
-    cfg.activation = P.activation; cfg.momentum_rule = P.momentum_rule; cfg.seed = P.dropout_seed; cfg.compute_dtype = P.compute_dtype;
-    cfg.max_chunk_frames = P.traincache;
-    if (P.gpu_used < 1) { printf("GPU Num %d Not In Range %d-\n", P.gpu_used, 1); exit(0); }      // BP_GPU.cu:20-24
-    if (P.device >= 0) cfg.device = P.device + (world > 1 ? rank : 0);
-    else if (world > 1) {
-        int ndev = 1;
-        if (bp_device_count(&ndev) != 0 || ndev < 1) { printf("%s\n", bp_last_error()); exit(0); }
-        cfg.device = rank % ndev;
-    }
-    if (lead) printf("Use GPU Device : %d\n", P.gpu_used);
-    BP_GPU *TrainObj = new BP_GPU(cfg, weights, bias, world, rank, dp_key.c_str());
     // Interface::get_pfile_info's progress lines (Interface.cc:479,512,528,536,554); the checks themselves ran in reader.open()
     fprintf(log, "begin to read in_pfile\nbegin to read target_pfile\n");
     fprintf(log, "tmpsentnum=%d,tmpframenum=%d,total_frames=%d\n", (int)reader.total_sents(), (int)reader.total_frames(), (int)reader.total_frames());
@@ -265,39 +236,81 @@ int main(int argc, char **argv)
     std::vector<int> chunk_index(nchunks);
     for (int i = 0; i < nchunks; ++i) chunk_index[i] = i;
     bp::PfileReader::rand_index(chunk_index.data(), nchunks);           // BPtrain.cc:47
+    if (P.gpu_used < 1) { printf("GPU Num %d Not In Range %d-\n", P.gpu_used, 1); exit(0); }      // BP_GPU.cu:20-24
+
+    // ---- fork the data-parallel ranks (everything above is inherited; nothing has touched the GPU yet)
+    bp::ChunkRing *ring = nullptr;
+    if (world > 1) {
+        int fcap = 1;
+        for (int c = 0; c < nchunks; ++c) { const int f = reader.chunk_shape(tp, c).n_frames; if (f > fcap) fcap = f; }
+        ring = new bp::ChunkRing(world, fcap, P.traincache, en - st + 2, P.fea_dim, P.layersizes[L - 1], reader.nat());
+        fflush(stdout); fflush(log);
+        for (int r = 1; r < world; ++r) {
+            const pid_t c = fork();
+            if (c < 0) { printf("fork failed\n"); exit(0); }
+            if (c == 0) { rank = r; kids.clear(); lead = false; log = fopen("/dev/null", "wt"); fp_out = nullptr; break; }
+            kids.push_back(c);
+        }
+    }
+
+    // ---- BPtrain.cc:31-96
+    bp_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.gpu_used = P.gpu_used > 0 ? P.gpu_used : 1; cfg.numlayers = L;
+    for (int i = 0; i < L; ++i) cfg.layersizes[i] = P.layersizes[i];
+    cfg.bunchsize = P.bunchsize / world;                    // BP_GPU.cu:29-36: the bunch is split over the GPUs
+    cfg.lrate = P.lrate; cfg.momentum = P.momentum; cfg.weightcost = P.weightcost;
+    cfg.dropoutflag = P.dropoutflag; cfg.visible_omit = P.visible_omit; cfg.hid_omit = P.hid_omit;
+    cfg.activation = P.activation; cfg.momentum_rule = P.momentum_rule; cfg.seed = P.dropout_seed; cfg.compute_dtype = P.compute_dtype;
+    cfg.max_chunk_frames = P.traincache;
+    if (P.device >= 0) cfg.device = P.device + (world > 1 ? rank : 0);
+    else if (world > 1) {
+        int ndev = 1;
+        if (bp_device_count(&ndev) != 0 || ndev < 1) { printf("%s\n", bp_last_error()); if (ring) ring->abort(); exit(0); }
+        cfg.device = rank % ndev;
+    }
+    if (lead) printf("Use GPU Device : %d\n", P.gpu_used);
+    BP_GPU *TrainObj = new BP_GPU(cfg, weights, bias, world, rank, dp_key.c_str());
     struct timespec ts0, ts1;
     clock_gettime(CLOCK_MONOTONIC, &ts0);
-    {
+    if (world > 1) {
+        // one reader per node: every rank's helper thread takes its part of producing each chunk into the shared ring
+        // (rank 0: tables + shuffle + noise-aware rows; everyone: 1/world of the frame conversion), the main thread
+        // consumes: this rank's rows of every global minibatch
+        if (!P.stack_on_device && lead) fprintf(log, "(gpu_used > 1: stack=host is not used, the context windows are built on the device)\n");
+        std::thread helper([&] {
+            for (int i = 0; i < nchunks; ++i)
+                if (!ring->produce(reader, tp, i, chunk_index[i], true, rank)) return;
+        });
+        for (int i = 0; i < nchunks; ++i) {
+            bp::ChunkRing::View v;
+            if (!ring->acquire(i, v)) { printf("bptrain: the data-parallel group was aborted\n"); fflush(stdout); _exit(3); }
+            fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, v.n_samples);
+            fflush(log);
+            const std::vector<int> rows = shard_rows(v.n_samples, P.bunchsize, world, rank);
+            if (lead && v.n_samples % P.bunchsize)
+                printf("this bunch has only %d samples and is ignored.\n", v.n_samples % P.bunchsize);   // BP_GPU.cu:317
+            std::vector<int> ws(rows.size()), tf(rows.size()), nr(v.nat_row ? rows.size() : 0);
+            for (size_t k = 0; k < rows.size(); ++k) {
+                ws[k] = v.win_start[rows[k]]; tf[k] = v.targ_frame[rows[k]];
+                if (v.nat_row) nr[k] = v.nat_row[rows[k]];
+            }
+            bp_window_chunk c;
+            memset(&c, 0, sizeof(c));
+            c.n_samples = (int)rows.size(); c.n_frames = v.n_frames; c.fea_dim = P.fea_dim; c.context = P.fea_context; c.n_nat = v.n_nat;
+            c.fea = v.fea; c.targ_frames = v.targ; c.nat = v.nat;
+            c.win_start = ws.data(); c.targ_frame = tf.data(); c.nat_row = v.nat_row ? nr.data() : nullptr;
+            TrainObj->train_windows(c);                     // returns once frames and tables are on the device: the slot is free
+            ring->done(i);
+        }
+        helper.join();
+    } else {
         ChunkStream chunks(reader, tp, chunk_index, true, P.prefetch);
         for (int i = 0; i < nchunks; ++i) {
             const WindowChunk &w = chunks.get(i);           // (the read of chunk i+1 is now running behind us)
             fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, w.n_samples);
             fflush(log);
-            if (world > 1) {
-                // this rank's rows of every global minibatch
-                const std::vector<int> rows = shard_rows(w.n_samples, P.bunchsize, world, rank);
-                if (lead && w.n_samples % P.bunchsize)
-                    printf("this bunch has only %d samples and is ignored.\n", w.n_samples % P.bunchsize);   // BP_GPU.cu:317
-                if (P.stack_on_device) {
-                    std::vector<int> ws(rows.size()), tf(rows.size()), nr(w.nat_row.empty() ? 0 : rows.size());
-                    for (size_t k = 0; k < rows.size(); ++k) {
-                        ws[k] = w.win_start[rows[k]]; tf[k] = w.targ_frame[rows[k]];
-                        if (!nr.empty()) nr[k] = w.nat_row[rows[k]];
-                    }
-                    bp_window_chunk c = describe(w, P.fea_context);
-                    c.n_samples = (int)rows.size(); c.win_start = ws.data(); c.targ_frame = tf.data(); c.nat_row = nr.empty() ? nullptr : nr.data();
-                    TrainObj->train_windows(c);             // (returns once the tables are on the device)
-                } else {
-                    reader.expand(w, indata.data(), targ.data());
-                    const int s0 = P.layersizes[0], sL = P.layersizes[L - 1];
-                    std::vector<float> xin(rows.size() * (size_t)s0), xtg(rows.size() * (size_t)sL);
-                    for (size_t k = 0; k < rows.size(); ++k) {
-                        memcpy(&xin[k * s0], &indata[(size_t)rows[k] * s0], sizeof(float) * s0);
-                        memcpy(&xtg[k * sL], &targ[(size_t)rows[k] * sL], sizeof(float) * sL);
-                    }
-                    TrainObj->train((int)rows.size(), xin.data(), xtg.data());
-                }
-            } else if (P.stack_on_device) {
+            if (P.stack_on_device) {
                 TrainObj->train_windows(describe(w, P.fea_context));
             } else {
                 reader.expand(w, indata.data(), targ.data());

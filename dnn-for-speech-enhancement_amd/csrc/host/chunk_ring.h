@@ -1,0 +1,132 @@
+// chunk_ring.h -- ONE reader per node for data-parallel training (bptrain gpu_used=N).
+//
+// The reference has one host reader feeding its G devices (Interface::Readchunk fills one host buffer, BP_GPU::train
+// splits it, Interface.cc:689-861, BP_GPU.cu:269-277).  With one process per GPU the naive equivalent makes every rank
+// read, byte-swap, normalise and window-plan the WHOLE chunk and then keep 1/N of its rows -- N times the host work, on
+// the cores that already limit a single GPU.  Here the ranks (forked from one parent) share a two-slot ring in anonymous
+// shared memory and split the work so that every Pfile byte is read ONCE per node:
+//     rank 0      builds the chunk's tables (window starts, target frames, noise-aware rows; consumes the lrand48
+//                 shuffle stream exactly as the single-process reader does), later its noise-aware block
+//     every rank  converts 1/N of the chunk's frames (positioned reads, byte swap, mean/variance normalisation) straight
+//                 into the shared slot
+//     every rank  then takes ITS rows of every global minibatch out of the shared tables and uploads
+// The result in the slot is bit-identical to PfileReader::read_chunk_windows (same pieces, tests/test_pfile_reader.py).
+// Slot i&1 is refilled while the other one trains.  A rank that dies raises `abort`, so the others fail instead of hang.
+#pragma once
+#include <atomic>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <unistd.h>
+#include <vector>
+
+#include "pfile_reader.h"
+
+namespace bp {
+
+// Rows of a chunk that rank `rank` of `world` trains on: its B = Bg/world frames of every full global minibatch
+// (rows i*Bg + rank*B ... of minibatch i; the partial last minibatch is dropped as in BP_GPU.cu:315-318).
+inline std::vector<int> shard_rows(int n_samples, int global_bunch, int world, int rank)
+{
+    const int B = global_bunch / world, nb = n_samples / global_bunch;
+    std::vector<int> idx((size_t)nb * B);
+    for (int i = 0; i < nb; ++i)
+        for (int j = 0; j < B; ++j) idx[(size_t)i * B + j] = i * global_bunch + rank * B + j;
+    return idx;
+}
+
+class ChunkRing {
+public:
+    struct View {                      // one ready chunk in a slot (valid until done(seq))
+        int n_samples, n_frames, n_nat;
+        const float *fea, *targ, *nat;
+        const int *win_start, *targ_frame, *nat_row;
+    };
+    // Call in the parent BEFORE forking the ranks: the mapping is inherited.  frames_cap / samples_cap: the largest chunk
+    // of the plan; nat_cap: an upper bound of noise-aware rows per chunk.
+    ChunkRing(int world, int frames_cap, int samples_cap, int nat_cap, int D, int OD, bool nat)
+        : world_(world), fcap_(frames_cap), scap_(samples_cap), ncap_(nat ? nat_cap : 0), D_(D), OD_(OD)
+    {
+        slot_floats_ = (size_t)fcap_ * D_ + (size_t)fcap_ * OD_ + (size_t)ncap_ * D_;
+        slot_bytes_ = ((slot_floats_ + 3 * (size_t)scap_) * 4 + 4095) & ~(size_t)4095;
+        bytes_ = 4096 + 2 * slot_bytes_;
+        void *p = mmap(nullptr, bytes_, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) die("cannot map %zu bytes of shared memory for the chunk ring", bytes_);
+        base_ = (char *)p;
+        hdr_ = new (base_) Hdr();
+        hdr_->abort.store(0);
+        for (int s = 0; s < 2; ++s) { hdr_->slot[s].tables_seq.store(-1); hdr_->slot[s].ready_seq.store(-1); hdr_->slot[s].converted.store(0); hdr_->slot[s].consumed.store(world); }
+    }
+    ~ChunkRing() { if (base_) munmap(base_, bytes_); }
+    void abort() { if (hdr_) hdr_->abort.store(1); }
+    bool aborted() const { return hdr_->abort.load() != 0; }
+
+    // The producer side of chunk number `seq` of the epoch (plan chunk `chunk_index`), run by EVERY rank in order
+    // seq = 0, 1, ... on a helper thread: rank 0 publishes the tables, everyone converts a slice, rank 0 finishes.
+    // Returns false when the group was aborted.
+    bool produce(PfileReader &r, const PfileReader::Plan &p, int seq, int chunk_index, bool shuffle, int rank)
+    {
+        Slot &s = hdr_->slot[seq & 1];
+        float *fea = slot_fea(seq & 1), *targ = fea + (size_t)fcap_ * D_, *nat = targ + (size_t)fcap_ * OD_;
+        int *ws = (int *)(nat + (size_t)ncap_ * D_), *tf = ws + scap_, *nr = tf + scap_;
+        const PfileReader::ChunkShape c = r.chunk_shape(p, chunk_index);
+        if (c.n_frames > fcap_ || c.n_samples > scap_) die("chunk ring: chunk %d exceeds the planned capacity", chunk_index);
+        if (rank == 0) {
+            if (!wait([&] { return s.consumed.load() == world_; })) return false;       // previous tenant fully consumed
+            s.converted.store(0); s.consumed.store(0);
+            std::vector<int> seg_start, seg_sent;
+            r.build_tables(p, chunk_index, shuffle, ws, tf, r.nat() ? nr : nullptr, seg_start, seg_sent);
+            if ((int)seg_start.size() > ncap_ && r.nat()) die("chunk ring: more noise-aware rows than planned");
+            s.n_samples = c.n_samples; s.n_frames = c.n_frames; s.n_nat = r.nat() ? (int)seg_start.size() : 0;
+            seg_start_ = seg_start; seg_sent_ = seg_sent;
+            s.tables_seq.store(seq);
+        }
+        if (!wait([&] { return s.tables_seq.load() == seq; })) return false;
+        const int lo = (int)((long)c.n_frames * rank / world_), hi = (int)((long)c.n_frames * (rank + 1) / world_);
+        r.convert_frames(p, chunk_index, c.frame_st, lo, hi, fea, targ);
+        s.converted.fetch_add(1);
+        if (rank == 0) {
+            if (!wait([&] { return s.converted.load() == world_; })) return false;
+            if (r.nat() && c.n_frames > 0) r.nat_rows(p, chunk_index, fea, seg_start_, seg_sent_, nat);
+            s.ready_seq.store(seq);
+        }
+        return true;
+    }
+    // consumer side (every rank's main thread): wait for chunk `seq`, use it, then done(seq)
+    bool acquire(int seq, View &v)
+    {
+        Slot &s = hdr_->slot[seq & 1];
+        if (!wait([&] { return s.ready_seq.load() == seq; })) return false;
+        float *fea = slot_fea(seq & 1), *targ = fea + (size_t)fcap_ * D_, *nat = targ + (size_t)fcap_ * OD_;
+        int *ws = (int *)(nat + (size_t)ncap_ * D_);
+        v.n_samples = s.n_samples; v.n_frames = s.n_frames; v.n_nat = s.n_nat;
+        v.fea = fea; v.targ = targ; v.nat = s.n_nat ? nat : nullptr;
+        v.win_start = ws; v.targ_frame = ws + scap_; v.nat_row = s.n_nat ? ws + 2 * scap_ : nullptr;
+        return true;
+    }
+    void done(int seq) { hdr_->slot[seq & 1].consumed.fetch_add(1); }
+
+private:
+    struct Slot { std::atomic<int> tables_seq, converted, ready_seq, consumed; int n_samples, n_frames, n_nat; };
+    struct Hdr { std::atomic<int> abort; Slot slot[2]; };
+    float *slot_fea(int s) const { return (float *)(base_ + 4096 + (size_t)s * slot_bytes_); }
+    template <class F> bool wait(F cond)
+    {
+        const time_t t0 = time(nullptr);
+        for (unsigned spins = 0; !cond(); ++spins) {
+            if (hdr_->abort.load()) return false;
+            if ((spins & 1023) == 1023 && time(nullptr) - t0 > 600) { hdr_->abort.store(1); return false; }   // a rank is gone
+            usleep(spins < 64 ? 20 : 200);
+        }
+        return true;
+    }
+    int world_, fcap_, scap_, ncap_, D_, OD_;
+    size_t slot_floats_, slot_bytes_, bytes_;
+    char *base_ = nullptr;
+    Hdr *hdr_ = nullptr;
+    std::vector<int> seg_start_, seg_sent_;       // rank 0's helper only
+};
+
+}  // namespace bp

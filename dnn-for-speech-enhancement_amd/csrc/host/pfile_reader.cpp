@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 namespace bp {
 
@@ -180,75 +181,95 @@ static void parallel_rows(int n, F body)
 
 int PfileReader::WindowChunk::n_nat() const { return fea_dim > 0 ? (int)(nat.size() / (size_t)fea_dim) : 0; }
 
-int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowChunk &w)
+// ---- the chunk reader in pieces, so that a node-level shared reader (chunk_ring.h: bptrain gpu_used=N) can have
+// rank 0 build the tables once and every rank convert a slice of the frames.  read_chunk_windows below is their
+// composition, so both paths produce identical chunks by construction.
+PfileReader::ChunkShape PfileReader::chunk_shape(const Plan &p, int ci) const
 {
-    const int D = cfg_.fea_dim, ctx = cfg_.fea_context, OD = cfg_.out_dim;
+    ChunkShape c;
     const int nchunks = (int)p.chunk_frame_st.size();
-    const int frame_st = p.chunk_frame_st[ci];
-    int frames_need, samples;
-    const bool inference = !p.chunk_frame_en.empty();
-    if (inference) {
-        frames_need = p.chunk_frame_en[ci] - frame_st;
-        samples = p.chunk_samples[ci];
+    c.frame_st = p.chunk_frame_st[ci];
+    if (!p.chunk_frame_en.empty()) {                       // plan_inference
+        c.n_frames = p.chunk_frame_en[ci] - c.frame_st;
+        c.n_samples = p.chunk_samples[ci];
     } else if (ci == nchunks - 1) {
-        frames_need = frames_before_sent_[p.sent_en] - frame_st;
-        samples = (int)p.total_samples - cfg_.traincache * ci;
+        c.n_frames = frames_before_sent_[p.sent_en] - c.frame_st;
+        c.n_samples = (int)p.total_samples - cfg_.traincache * ci;
     } else {
-        frames_need = p.chunk_frame_st[ci + 1] - frame_st;
-        samples = cfg_.traincache;
+        c.n_frames = p.chunk_frame_st[ci + 1] - c.frame_st;
+        c.n_samples = cfg_.traincache;
     }
-    w.fea_dim = D;
-    w.n_samples = samples > 0 ? samples : 0;
-    w.n_frames = 0;
-    w.nat.clear();
-    w.win_start.assign(w.n_samples, 0); w.targ_frame.assign(w.n_samples, 0); w.nat_row.assign(nat_ ? w.n_samples : 0, 0);
-    std::vector<int> sample_index(w.n_samples);
-    for (int i = 0; i < w.n_samples; ++i) sample_index[i] = i;
-    if (shuffle) rand_index(sample_index.data(), samples);
-    if (frames_need <= 0 || samples <= 0) return w.n_samples;
-    w.n_frames = frames_need;
+    if (c.n_samples < 0) c.n_samples = 0;
+    if (c.n_frames <= 0 || c.n_samples == 0) c.n_frames = 0;
+    return c;
+}
 
-    // ---- features: big-endian records {sent_id, frame_id, feat[D]} -> mean/variance normalised floats
-    std::vector<uint32_t> &raw = raw_;
-    raw.resize((size_t)frames_need * (D + 2));
-    if (fseek(fp_data_, PFILE_HEADER_SIZE + (long)frame_st * (long)sizeof(float) * (D + 2), SEEK_SET) != 0)
-        die("data pfile cannot fseek to chunk %d.", ci);
-    if (fread(raw.data(), sizeof(float) * (D + 2), frames_need, fp_data_) != (size_t)frames_need)
-        die("data pfile: short read in chunk %d.", ci);
-    const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
-    // The id indexes the sentence table below.  The reference trusts it; a corrupt or mismatched Pfile would make us read
-    // outside the table (or silently build wrong windows), so it must lie in the planned range and own the chunk's first frame.
-    if (first_sent < p.sent_st || first_sent > p.sent_en || first_sent >= (int)total_sents_ || frames_before_sent_[first_sent] <= frame_st ||
-        (first_sent > 0 && frames_before_sent_[first_sent - 1] > frame_st))
-        die("data pfile: record %d carries sentence id %d, which does not contain that frame (sentences %d-%d planned).", frame_st, first_sent, p.sent_st, p.sent_en);
-    w.fea.resize((size_t)frames_need * D);
-    parallel_rows(frames_need, [&](int lo, int hi) {
-        for (int i = lo; i < hi; ++i)
+static void pread_all(FILE *fp, void *dst, size_t bytes, long off, const char *what, int ci)
+{
+    char *d = (char *)dst;
+    while (bytes > 0) {
+        const ssize_t n = pread(fileno(fp), d, bytes, off);
+        if (n <= 0) die("%s pfile: short read in chunk %d.", what, ci);
+        d += n; off += n; bytes -= (size_t)n;
+    }
+}
+
+// frames [lo, hi) of the chunk that starts at file frame frame_st: big-endian records {sent_id, frame_id, feat[D]} ->
+// mean/variance normalised features at fea + lo*D, raw targets (not normalised, Interface.cc:815-816) at targ + lo*OD.
+// Positioned reads only (no shared file offset): several threads / forked processes may convert slices at once.
+void PfileReader::convert_frames(const Plan &p, int ci, int frame_st, int lo, int hi, float *fea, float *targ) const
+{
+    const int D = cfg_.fea_dim, OD = cfg_.out_dim, n = hi - lo;
+    if (n <= 0) return;
+    std::vector<uint32_t> raw((size_t)n * (D + 2));
+    pread_all(fp_data_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo) * (long)sizeof(float) * (D + 2), "data", ci);
+    if (lo == 0) {
+        const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
+        // The id indexes the sentence table.  The reference trusts it; a corrupt or mismatched Pfile would make us read
+        // outside the table (or silently build wrong windows), so it must lie in the planned range and own the chunk's first frame.
+        if (first_sent < p.sent_st || first_sent > p.sent_en || first_sent >= (int)total_sents_ || frames_before_sent_[first_sent] <= frame_st ||
+            (first_sent > 0 && frames_before_sent_[first_sent - 1] > frame_st))
+            die("data pfile: record %d carries sentence id %d, which does not contain that frame (sentences %d-%d planned).", frame_st, first_sent, p.sent_st, p.sent_en);
+    }
+    parallel_rows(n, [&](int a, int b) {
+        for (int i = a; i < b; ++i)
             for (int j = 0; j < D; ++j) {
                 const uint32_t x = bswap(raw[(size_t)i * (D + 2) + 2 + j]);
                 float v; memcpy(&v, &x, 4);
                 v -= mean_[j];
                 v *= dvar_[j];
-                w.fea[(size_t)i * D + j] = v;
+                fea[(size_t)(lo + i) * D + j] = v;
             }
     });
-    // ---- targets (not normalised, Interface.cc:815-816)
-    w.targ.resize((size_t)frames_need * OD);
-    if (fseek(fp_targ_, PFILE_HEADER_SIZE + (long)frame_st * (long)sizeof(float) * (OD + 2), SEEK_SET) != 0)
-        die("targ pfile cannot fseek to chunk %d.", ci);
-    raw.resize((size_t)frames_need * (OD + 2));
-    if (fread(raw.data(), sizeof(float) * (OD + 2), frames_need, fp_targ_) != (size_t)frames_need)
-        die("targ pfile: short read in chunk %d.", ci);
-    parallel_rows(frames_need, [&](int lo, int hi) {
-        for (int i = lo; i < hi; ++i)
+    if (!targ) return;
+    raw.resize((size_t)n * (OD + 2));
+    pread_all(fp_targ_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo) * (long)sizeof(float) * (OD + 2), "targ", ci);
+    parallel_rows(n, [&](int a, int b) {
+        for (int i = a; i < b; ++i)
             for (int j = 0; j < OD; ++j) {
                 const uint32_t x = bswap(raw[(size_t)i * (OD + 2) + 2 + j]);
-                memcpy(&w.targ[(size_t)i * OD + j], &x, 4);
+                memcpy(&targ[(size_t)(lo + i) * OD + j], &x, 4);
             }
     });
+}
 
-    // ---- samples: per sentence segment inside the chunk, ctx stacked frames (oldest first) [+ NAT block]
-    int frames_processed = 0, cur_frame_id = frame_st, cur_sample = 0, cur_sent = first_sent;
+// per-sample tables of the chunk (consumes the lrand48 stream when shuffle): samples per sentence segment inside the
+// chunk, ctx stacked frames (oldest first).  seg_start / seg_sent: first chunk-relative frame and sentence of every
+// segment that owns at least one window (one noise-aware row each, in this order).
+void PfileReader::build_tables(const Plan &p, int ci, bool shuffle, int *win_start, int *targ_frame, int *nat_row,
+                               std::vector<int> &seg_start, std::vector<int> &seg_sent)
+{
+    const ChunkShape c = chunk_shape(p, ci);
+    const int ctx = cfg_.fea_context, frames_need = c.n_frames, samples = c.n_samples, frame_st = c.frame_st;
+    seg_start.clear(); seg_sent.clear();
+    std::vector<int> sample_index(samples);
+    for (int i = 0; i < samples; ++i) sample_index[i] = i;
+    if (shuffle) rand_index(sample_index.data(), samples);
+    for (int i = 0; i < samples; ++i) { win_start[i] = 0; targ_frame[i] = 0; if (nat_row) nat_row[i] = 0; }
+    if (frames_need <= 0 || samples <= 0) return;
+    // the sentence that owns the chunk's first frame (the reader cross-checks the record's own id in convert_frames)
+    int cur_sent = (int)(std::upper_bound(frames_before_sent_.begin(), frames_before_sent_.end(), frame_st) - frames_before_sent_.begin());
+    int frames_processed = 0, cur_frame_id = frame_st, cur_sample = 0;
     while (frames_processed != frames_need && cur_sent < (int)total_sents_) {
         int seg;
         if (frames_before_sent_[cur_sent] > frames_need + frame_st) seg = frames_need - frames_processed;
@@ -256,54 +277,17 @@ int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowC
         int nat_id = -1;
         for (int j = 0; j <= seg - ctx && cur_sample < samples; ++j) {
             const int pos = sample_index[cur_sample];
-            w.win_start[pos] = frames_processed + j;
-            if (nat_) {
-                if (nat_id < 0) {
-                    // noise-aware training: mean of the segment's first 6 normalised frames, summed left to right
-                    // and divided by 6.0f (Interface.cc:776-779, generalised from the literal 129 to fea_dim)
-                    nat_id = w.n_nat();
-                    w.nat.resize(w.nat.size() + (size_t)D);
-                    float *nrow = &w.nat[(size_t)nat_id * D];
-                    const int sent_begin = cur_sent == 0 ? 0 : frames_before_sent_[cur_sent - 1];
-                    if (inference && cur_frame_id > sent_begin) {
-                        // a later piece of a sentence split by plan_inference: the noise estimate is still the mean of the
-                        // SENTENCE's first 6 frames, which lie before this chunk -- fetch and normalise just those
-                        const int nf = std::min(6, frames_before_sent_[cur_sent] - sent_begin);
-                        std::vector<uint32_t> head((size_t)nf * (D + 2));
-                        const long keep = ftell(fp_data_);
-                        if (fseek(fp_data_, PFILE_HEADER_SIZE + (long)sent_begin * (long)sizeof(float) * (D + 2), SEEK_SET) != 0 ||
-                            fread(head.data(), sizeof(float) * (D + 2), nf, fp_data_) != (size_t)nf)
-                            die("data pfile: cannot read the first frames of sentence %d.", cur_sent);
-                        fseek(fp_data_, keep, SEEK_SET);
-                        for (int k = 0; k < D; ++k) {
-                            float sacc = 0.0f;
-                            for (int f = 0; f < 6; ++f) {
-                                const uint32_t x = bswap(head[(size_t)(f < nf ? f : nf - 1) * (D + 2) + 2 + k]);
-                                float v; memcpy(&v, &x, 4);
-                                v -= mean_[k]; v *= dvar_[k];
-                                sacc = f == 0 ? v : sacc + v;
-                            }
-                            nrow[k] = sacc / 6.0f;
-                        }
-                    } else
-                    for (int k = 0; k < D; ++k) {
-                        float s = 0.0f;
-                        for (int f = 0; f < 6; ++f) {
-                            int fr = frames_processed + f;
-                            if (fr >= frames_need) fr = frames_need - 1;          // (the reference reads past its buffer here)
-                            s = f == 0 ? w.fea[(size_t)fr * D + k] : s + w.fea[(size_t)fr * D + k];
-                        }
-                        nrow[k] = s / 6.0f;
-                    }
-                }
-                w.nat_row[pos] = nat_id;
+            win_start[pos] = frames_processed + j;
+            if (nat_row) {
+                if (nat_id < 0) { nat_id = (int)seg_start.size(); seg_start.push_back(frames_processed); seg_sent.push_back(cur_sent); }
+                nat_row[pos] = nat_id;
             }
             int tf = frames_processed + j + cfg_.targ_offset;
             if (tf >= frames_need) {                     // (the reference reads past its buffer here)
                 if (!clamp_warned_) { fprintf(stderr, "pfile_reader: targ_offset %d points past the chunk's last frame; clamped (check targ_offset)\n", cfg_.targ_offset); clamp_warned_ = true; }
                 tf = frames_need - 1;
             }
-            w.targ_frame[pos] = tf;
+            targ_frame[pos] = tf;
             ++cur_sample;
         }
         cur_frame_id = frames_before_sent_[cur_sent];
@@ -312,6 +296,68 @@ int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowC
     }
     // samples the segment walk did not reach (cannot happen with a consistent plan) keep window 0: the stacked
     // reader would have left stale rows there
+}
+
+// noise-aware training: one row per segment = mean of the segment's first 6 normalised frames, summed left to right
+// and divided by 6.0f (Interface.cc:776-779, generalised from the literal 129 to fea_dim)
+void PfileReader::nat_rows(const Plan &p, int ci, const float *fea, const std::vector<int> &seg_start, const std::vector<int> &seg_sent, float *nat) const
+{
+    const ChunkShape c = chunk_shape(p, ci);
+    const int D = cfg_.fea_dim, frames_need = c.n_frames;
+    const bool inference = !p.chunk_frame_en.empty();
+    for (size_t sg = 0; sg < seg_start.size(); ++sg) {
+        float *nrow = nat + sg * (size_t)D;
+        const int cur_sent = seg_sent[sg], sent_begin = cur_sent == 0 ? 0 : frames_before_sent_[cur_sent - 1];
+        if (inference && c.frame_st + seg_start[sg] > sent_begin) {
+            // a later piece of a sentence split by plan_inference: the noise estimate is still the mean of the
+            // SENTENCE's first 6 frames, which lie before this chunk -- fetch and normalise just those
+            const int nf = std::min(6, frames_before_sent_[cur_sent] - sent_begin);
+            std::vector<uint32_t> head((size_t)nf * (D + 2));
+            pread_all(fp_data_, head.data(), head.size() * 4, PFILE_HEADER_SIZE + (long)sent_begin * (long)sizeof(float) * (D + 2), "data", ci);
+            for (int k = 0; k < D; ++k) {
+                float sacc = 0.0f;
+                for (int f = 0; f < 6; ++f) {
+                    const uint32_t x = bswap(head[(size_t)(f < nf ? f : nf - 1) * (D + 2) + 2 + k]);
+                    float v; memcpy(&v, &x, 4);
+                    v -= mean_[k]; v *= dvar_[k];
+                    sacc = f == 0 ? v : sacc + v;
+                }
+                nrow[k] = sacc / 6.0f;
+            }
+            continue;
+        }
+        for (int k = 0; k < D; ++k) {
+            float s = 0.0f;
+            for (int f = 0; f < 6; ++f) {
+                int fr = seg_start[sg] + f;
+                if (fr >= frames_need) fr = frames_need - 1;          // (the reference reads past its buffer here)
+                s = f == 0 ? fea[(size_t)fr * D + k] : s + fea[(size_t)fr * D + k];
+            }
+            nrow[k] = s / 6.0f;
+        }
+    }
+}
+
+int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowChunk &w)
+{
+    const int D = cfg_.fea_dim, OD = cfg_.out_dim;
+    const ChunkShape c = chunk_shape(p, ci);
+    w.fea_dim = D;
+    w.n_samples = c.n_samples;
+    w.n_frames = c.n_frames;
+    w.nat.clear();
+    w.win_start.assign(w.n_samples, 0); w.targ_frame.assign(w.n_samples, 0); w.nat_row.assign(nat_ ? w.n_samples : 0, 0);
+    std::vector<int> seg_start, seg_sent;
+    // (tables first: the shuffle consumes lrand48 before any file access, as Readchunk does, Interface.cc:700-704)
+    build_tables(p, ci, shuffle, w.win_start.data(), w.targ_frame.data(), nat_ ? w.nat_row.data() : nullptr, seg_start, seg_sent);
+    if (c.n_frames <= 0) return w.n_samples;
+    w.fea.resize((size_t)c.n_frames * D);
+    w.targ.resize((size_t)c.n_frames * OD);
+    convert_frames(p, ci, c.frame_st, 0, c.n_frames, w.fea.data(), w.targ.data());
+    if (nat_) {
+        w.nat.resize(seg_start.size() * (size_t)D);
+        nat_rows(p, ci, w.fea.data(), seg_start, seg_sent, w.nat.data());
+    }
     return w.n_samples;
 }
 

@@ -60,6 +60,17 @@ public:
         int fea_dim = 0;
     };
     int read_chunk_windows(const Plan &p, int chunk_index, bool shuffle, WindowChunk &out);
+    // The same in pieces (read_chunk_windows is their composition), for a node-level shared reader (chunk_ring.h):
+    // tables once, frame conversion in slices by whoever has cores to spare.  convert_frames / nat_rows use positioned
+    // reads only and may run concurrently in several threads or forked processes.
+    struct ChunkShape { int frame_st = 0, n_frames = 0, n_samples = 0; };
+    ChunkShape chunk_shape(const Plan &p, int chunk_index) const;
+    void convert_frames(const Plan &p, int chunk_index, int frame_st, int lo, int hi, float *fea, float *targ) const;
+    void build_tables(const Plan &p, int chunk_index, bool shuffle, int *win_start, int *targ_frame, int *nat_row,
+                      std::vector<int> &seg_start, std::vector<int> &seg_sent);
+    void nat_rows(const Plan &p, int chunk_index, const float *fea, const std::vector<int> &seg_start, const std::vector<int> &seg_sent, float *nat) const;
+    int fea_dim() const { return cfg_.fea_dim; }
+    int out_dim() const { return cfg_.out_dim; }
     // host-side expansion of a window chunk into stacked rows (what Interface::Readchunk leaves in its buffers)
     void expand(const WindowChunk &w, float *in, float *targ) const;
     unsigned total_frames() const { return total_frames_; }
@@ -75,7 +86,6 @@ private:
     unsigned total_frames_ = 0, total_sents_ = 0;
     std::vector<int> frames_before_sent_;
     std::vector<float> mean_, dvar_;
-    std::vector<uint32_t> raw_;       // file-record scratch, kept across chunks
     bool nat_ = false;
     bool clamp_warned_ = false;
 };

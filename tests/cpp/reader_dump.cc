@@ -14,6 +14,9 @@
 #include <vector>
 #include "../../dnn-for-speech-enhancement_amd/csrc/host/pfile_reader.h"
 #include "../../dnn-for-speech-enhancement_amd/csrc/host/wts_io.h"
+#include "../../dnn-for-speech-enhancement_amd/csrc/host/chunk_ring.h"
+#include <sys/wait.h>
+#include <thread>
 
 int main(int argc, char **argv)
 {
@@ -39,6 +42,53 @@ int main(int argc, char **argv)
         }
         fclose(o);
         return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "ring") && argc == 17) {
+        // reader_dump ring <fea> <targ> <norm> <fea_dim> <ctx> <targ_offset> <out_dim> <traincache> <input_dim> <sent_st> <sent_en>
+        //                  <seed> <world> <global_bunch> <out_prefix>
+        //   the node-level shared reader of `bptrain gpu_used=N` (chunk_ring.h) WITHOUT a GPU: the parent opens, plans and
+        //   maps the ring, forks world-1 ranks; every rank helps produce each chunk and writes the stacked rows of ITS
+        //   shard to <out_prefix>.rank<r>: per chunk int32 n_rows, float in[n_rows*input_dim], targ[n_rows*out_dim]
+        bp::ReaderConfig rc;
+        rc.fea_file = argv[2]; rc.targ_file = argv[3]; rc.norm_file = argv[4];
+        rc.fea_dim = atoi(argv[5]); rc.fea_context = atoi(argv[6]); rc.targ_offset = atoi(argv[7]); rc.out_dim = atoi(argv[8]);
+        rc.traincache = atoi(argv[9]); rc.input_dim = atoi(argv[10]);
+        const int st = atoi(argv[11]), en = atoi(argv[12]), world = atoi(argv[14]), Bg = atoi(argv[15]);
+        srand48(atoi(argv[13]));
+        bp::PfileReader r(rc);
+        r.open();
+        const bp::PfileReader::Plan p = r.plan(st, en);
+        const int nch = (int)p.chunk_frame_st.size();
+        int fcap = 1;
+        for (int c = 0; c < nch; ++c) { const int f = r.chunk_shape(p, c).n_frames; if (f > fcap) fcap = f; }
+        bp::ChunkRing ring(world, fcap, rc.traincache, en - st + 2, rc.fea_dim, rc.out_dim, r.nat());
+        int rank = 0;
+        std::vector<pid_t> kids;
+        for (int k = 1; k < world; ++k) { const pid_t c = fork(); if (c == 0) { rank = k; kids.clear(); break; } kids.push_back(c); }
+        std::thread helper([&] { for (int i = 0; i < nch; ++i) if (!ring.produce(r, p, i, i, true, rank)) return; });
+        FILE *o = fopen((std::string(argv[16]) + ".rank" + std::to_string(rank)).c_str(), "wb");
+        const int D = rc.fea_dim, ctx = rc.fea_context, OD = rc.out_dim, s0 = rc.input_dim;
+        for (int i = 0; i < nch; ++i) {
+            bp::ChunkRing::View v;
+            if (!ring.acquire(i, v)) return 5;
+            const std::vector<int> rows = bp::shard_rows(v.n_samples, Bg, world, rank);
+            const int n = (int)rows.size();
+            fwrite(&n, 4, 1, o);
+            std::vector<float> in((size_t)n * s0), tg((size_t)n * OD);
+            for (int k = 0; k < n; ++k) {
+                memcpy(&in[(size_t)k * s0], v.fea + (size_t)v.win_start[rows[k]] * D, sizeof(float) * (size_t)ctx * D);
+                if (v.nat_row) memcpy(&in[(size_t)k * s0 + (size_t)ctx * D], v.nat + (size_t)v.nat_row[rows[k]] * D, sizeof(float) * D);
+                memcpy(&tg[(size_t)k * OD], v.targ + (size_t)v.targ_frame[rows[k]] * OD, sizeof(float) * OD);
+            }
+            fwrite(in.data(), 4, in.size(), o); fwrite(tg.data(), 4, tg.size(), o);
+            ring.done(i);
+        }
+        fclose(o);
+        helper.join();
+        if (rank != 0) _exit(0);
+        int bad = 0;
+        for (pid_t c : kids) { int stt = 0; waitpid(c, &stt, 0); if (!WIFEXITED(stt) || WEXITSTATUS(stt) != 0) bad = 1; }
+        return bad ? 6 : 0;
     }
     if (argc > 1 && !strcmp(argv[1], "infer") && argc == 14) {
         // reader_dump infer <fea> <norm> <fea_dim> <ctx> <targ_offset> <traincache> <input_dim> <sent_st> <sent_en> <out.bin> x x

@@ -102,6 +102,51 @@ def test_inference_planner_emits_every_window_once(tmp_path, dump_exe, D, ctx, c
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("world,Bg", [(2, 4), (3, 6), (8, 8)])
+@pytest.mark.parametrize("D,ctx,toff,OD,cache,nat,lens", [
+    (6, 3, 1, 3, 16, True, [10, 2, 7, 15, 4, 9, 22, 13]),         # cuts mid-sentence, short sentence, noise-aware rows
+    (5, 1, 0, 4, 24, False, [6, 9, 3, 12, 5, 30, 8]),
+])
+def test_one_reader_per_node_ring_equals_the_single_reader(tmp_path, dump_exe, world, Bg, D, ctx, toff, OD, cache, nat, lens):
+    """bptrain gpu_used=N (chunk_ring.h): N forked ranks share ONE reader -- rank 0 builds the tables (and consumes the
+    lrand48 shuffle stream), every rank converts 1/N of the frames, each takes its rows of every global minibatch.
+    What rank r would upload must be exactly rows i*Bg + r*Bg/N ... of the chunks the single-process reader produces
+    with the same seed (partial last minibatch dropped, BP_GPU.cu:315-318)."""
+    rs = np.random.default_rng(9)
+    n = sum(lens)
+    fea = rs.normal(size=(n, D)).astype(np.float32) * 3 + 1
+    tg = rs.normal(size=(n, OD)).astype(np.float32)
+    mean = rs.normal(size=D).astype(np.float32)
+    istd = (0.5 + rs.random(size=D)).astype(np.float32)
+    fp, tp, npth, out, pref = (str(tmp_path / x) for x in ("f.pfile", "t.pfile", "n.norm", "o.bin", "ring"))
+    PU.write_pfile(fp, lens, fea); PU.write_pfile(tp, lens, tg); PU.write_norm(npth, mean, istd)
+    s0 = D * (ctx + 1) if nat else D * ctx
+    common = [fp, tp, npth, str(D), str(ctx), str(toff), str(OD), str(cache), str(s0), "0", str(len(lens) - 1)]
+    subprocess.check_call([dump_exe, "chunks"] + common + ["1", "77", out])
+    subprocess.check_call([dump_exe, "ring"] + common + ["77", str(world), str(Bg), pref], timeout=120)
+    raw = np.fromfile(out, np.uint8)
+    nch = int(np.frombuffer(raw, np.int32, 1, 0)[0])
+    o, chunks = 8 + 4 * nch, []
+    for _ in range(nch):
+        cnt = int(np.frombuffer(raw, np.int32, 1, o)[0]); o += 4
+        xin = np.frombuffer(raw, np.float32, cnt * s0, o).reshape(cnt, s0); o += 4 * cnt * s0
+        xtg = np.frombuffer(raw, np.float32, cnt * OD, o).reshape(cnt, OD); o += 4 * cnt * OD
+        chunks.append((xin, xtg))
+    lb = Bg // world
+    for r in range(world):
+        rr = np.fromfile(pref + ".rank%d" % r, np.uint8)
+        o = 0
+        for xin, xtg in chunks:
+            nb = xin.shape[0] // Bg
+            rows = (np.arange(nb)[:, None] * Bg + r * lb + np.arange(lb)[None, :]).reshape(-1)
+            cnt = int(np.frombuffer(rr, np.int32, 1, o)[0]); o += 4
+            assert cnt == rows.size
+            gin = np.frombuffer(rr, np.float32, cnt * s0, o).reshape(cnt, s0); o += 4 * cnt * s0
+            gtg = np.frombuffer(rr, np.float32, cnt * OD, o).reshape(cnt, OD); o += 4 * cnt * OD
+            assert np.array_equal(gin, xin[rows]) and np.array_equal(gtg, xtg[rows]), ("rank", r)
+        assert o == rr.size
+
+
 def test_weight_file_bytes_and_roundtrip(tmp_path, dump_exe):
     ls = [6, 4, 3]
     rs = np.random.default_rng(1)
