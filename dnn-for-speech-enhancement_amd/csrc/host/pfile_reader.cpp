@@ -221,33 +221,34 @@ void PfileReader::convert_frames(const Plan &p, int ci, int frame_st, int lo, in
 {
     const int D = cfg_.fea_dim, OD = cfg_.out_dim, n = hi - lo;
     if (n <= 0) return;
-    std::vector<uint32_t> raw((size_t)n * (D + 2));
-    pread_all(fp_data_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo) * (long)sizeof(float) * (D + 2), "data", ci);
-    if (lo == 0) {
-        const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
-        // The id indexes the sentence table.  The reference trusts it; a corrupt or mismatched Pfile would make us read
-        // outside the table (or silently build wrong windows), so it must lie in the planned range and own the chunk's first frame.
-        if (first_sent < p.sent_st || first_sent > p.sent_en || first_sent >= (int)total_sents_ || frames_before_sent_[first_sent] <= frame_st ||
-            (first_sent > 0 && frames_before_sent_[first_sent - 1] > frame_st))
-            die("data pfile: record %d carries sentence id %d, which does not contain that frame (sentences %d-%d planned).", frame_st, first_sent, p.sent_st, p.sent_en);
-    }
+    // every worker reads AND converts its own rows: the copy out of the page cache (2 x 105 MB for a 102400-frame chunk
+    // of 257-bin frames) is as expensive as the arithmetic, and a single positioned read of the whole chunk made it the
+    // serial part of the reader (1.0 M frames/s end to end against 1.16 M for the GPU alone, round 2)
     parallel_rows(n, [&](int a, int b) {
+        std::vector<uint32_t> raw((size_t)(b - a) * (D + 2));
+        pread_all(fp_data_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo + a) * (long)sizeof(float) * (D + 2), "data", ci);
+        if (lo + a == 0) {
+            const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
+            // The id indexes the sentence table.  The reference trusts it; a corrupt or mismatched Pfile would make us read
+            // outside the table (or silently build wrong windows), so it must lie in the planned range and own the chunk's first frame.
+            if (first_sent < p.sent_st || first_sent > p.sent_en || first_sent >= (int)total_sents_ || frames_before_sent_[first_sent] <= frame_st ||
+                (first_sent > 0 && frames_before_sent_[first_sent - 1] > frame_st))
+                die("data pfile: record %d carries sentence id %d, which does not contain that frame (sentences %d-%d planned).", frame_st, first_sent, p.sent_st, p.sent_en);
+        }
         for (int i = a; i < b; ++i)
             for (int j = 0; j < D; ++j) {
-                const uint32_t x = bswap(raw[(size_t)i * (D + 2) + 2 + j]);
+                const uint32_t x = bswap(raw[(size_t)(i - a) * (D + 2) + 2 + j]);
                 float v; memcpy(&v, &x, 4);
                 v -= mean_[j];
                 v *= dvar_[j];
                 fea[(size_t)(lo + i) * D + j] = v;
             }
-    });
-    if (!targ) return;
-    raw.resize((size_t)n * (OD + 2));
-    pread_all(fp_targ_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo) * (long)sizeof(float) * (OD + 2), "targ", ci);
-    parallel_rows(n, [&](int a, int b) {
+        if (!targ) return;
+        raw.resize((size_t)(b - a) * (OD + 2));
+        pread_all(fp_targ_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo + a) * (long)sizeof(float) * (OD + 2), "targ", ci);
         for (int i = a; i < b; ++i)
             for (int j = 0; j < OD; ++j) {
-                const uint32_t x = bswap(raw[(size_t)i * (OD + 2) + 2 + j]);
+                const uint32_t x = bswap(raw[(size_t)(i - a) * (OD + 2) + 2 + j]);
                 memcpy(&targ[(size_t)(lo + i) * OD + j], &x, 4);
             }
     });

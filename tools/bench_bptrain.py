@@ -2,7 +2,7 @@
 """End-to-end rate of the BPtrain-compatible command line on a synthetic Pfile pair (reader + upload + GPU),
 C2 geometry: 257-dim frames, 11-frame context, 2827->2048x3->257, ReLU + dropout, bunch 256, traincache 102400.
 
-    python tools/bench_bptrain.py [n_sentences] [frames_per_sentence]
+    python tools/bench_bptrain.py [n_sentences] [frames_per_sentence] [--dp]
 
 Compares  stack=device (raw frames + index tables, windows built on the GPU; default of bptrain)
 with      stack=host   (the reference's layout: 11x stacked rows built and uploaded by the host),
@@ -39,8 +39,9 @@ def write_pfile_fast(path, sent_lens, data):
 
 
 def main():
-    nsent = int(sys.argv[1]) if len(sys.argv) > 1 else 500
-    flen = int(sys.argv[2]) if len(sys.argv) > 2 else 420
+    pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+    nsent = int(pos[0]) if len(pos) > 0 else 500
+    flen = int(pos[1]) if len(pos) > 1 else 420
     D, ctx = 257, 11
     ls = [D * ctx, 2048, 2048, 2048, D]
     rs = np.random.default_rng(1)
@@ -60,8 +61,12 @@ def main():
             "bunchsize=256", "gpu_used=1", "init_randem_seed=27863875", "momentum=0.5", "weightcost=0", "lrate=0.001",
             "visible_omit=0.1", "hid_omit=0.2", "layersizes=%s" % ",".join(map(str, ls)),
             "init_randem_weight_max=0.03", "init_randem_weight_min=-0.03", "init_randem_bias_max=0", "init_randem_bias_min=0"]
-    for mode, extra in (("stack=device prefetch=1", []), ("stack=device prefetch=0", ["prefetch=0"]),
-                        ("stack=host prefetch=1", ["stack=host"]), ("stack=host prefetch=0", ["stack=host", "prefetch=0"])):
+    # gpu_used=N (ranks share the devices that exist): ONE reader per node -- the shared chunk ring of chunk_ring.h; the
+    # node-level rate the reader side sustains is what "frames_per_s" shows once the GPUs stop being the limit
+    dp_modes = [("gpu_used=%d one reader per node (bunchsize %d global)" % (g, 256 * g), ["gpu_used=%d" % g, "bunchsize=%d" % (256 * g)])
+                for g in (2, 4, 8)] if "--dp" in sys.argv else []
+    for mode, extra in [("stack=device prefetch=1", []), ("stack=device prefetch=0", ["prefetch=0"]),
+                        ("stack=host prefetch=1", ["stack=host"]), ("stack=host prefetch=0", ["stack=host", "prefetch=0"])] + dp_modes:
         log = os.path.join(tmp, "log")
         t0 = time.time()
         r = subprocess.run([EXE] + base + ["outwts_file=%s/w" % tmp, "log_file=" + log] + extra, capture_output=True, text=True)
