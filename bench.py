@@ -130,6 +130,33 @@ def torch_cpu_line(W, b, budget_s=6.0):
             "sample": "%d C2 steps with torch CPU ops, %.1f s" % (n, dt)}
 
 
+def kernel_source_stamp():
+    """sha256[:16] over the kernel sources, as tools/profile_r03.sh stamps its PMC summaries: tells whether a traffic
+    figure read from profiles/ was measured on the kernels this run executes."""
+    import glob
+    import hashlib
+    d = os.path.join(ROOT, "dnn-for-speech-enhancement_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(d, "*.h"))) + sorted(glob.glob(os.path.join(d, "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(fname, match):
+    """(bytes per launch, stamp dict) of the first kernel whose key satisfies `match` in a tools/pmc_summary.py file."""
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", fname)))
+    except Exception:
+        return None, None
+    note = pm.get("note", "")
+    stamp = note.split("sha256[:16] ")[1].split(";")[0] if "sha256[:16] " in note else None
+    for k, v in pm.get("kernels", {}).items():
+        if match(k) and "fetch_MB_corrected_x2" in v and "write_MB" in v:
+            return (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6, {"source": "profiles/" + fname, "kernel": k, "sources_sha": stamp,
+                                                                      "matches_current_kernel_sources": stamp == kernel_source_stamp() if stamp else None}
+    return None, None
+
+
 def c5_line(dnnse_amd, dev, steps=40):
     """BASELINE.json configs[4] per-GPU shape (2827->4096x5->257, 512 frames per GPU, bf16 operands, fp32
     master weights) on this one GPU: step time and its HBM roofline (the step is HBM-bound)."""
@@ -153,10 +180,27 @@ def c5_line(dnnse_amd, dev, steps=40):
     # algorithmic bytes per step of the bf16 mode (lower figure): bf16 weights read by fwd and dgrad
     # (2P + 2(P - s0 s1)), fp32 W and delta read + written by the fused update (16P), bf16 shadow refresh (2P)
     alg = 22.0 * P - 2.0 * C5_LAYERS[0] * C5_LAYERS[1]
+    # HBM-side bytes of the step from the committed PMC pass (tools/profile_r03.sh): every kernel of one step summed
+    traffic, tstamp = None, None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_c5_pmc_hbm_traffic.json")))
+        tot, steps_prof = 0.0, None
+        for k, v in pm["kernels"].items():
+            if k.startswith(("void bp_gemm_bf16", "void bp_wgrad_dma_bf16", "bp_bias_bf16", "bp_to_bf16_both")) and "fetch_MB_corrected_x2" in v and "write_MB" in v:
+                tot += (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6 * v["launches"]
+                if k.startswith("void bp_wgrad_dma_bf16") and "false, 2" in k:
+                    steps_prof = v["launches"]                     # one launch of the large-tile group per step
+        if steps_prof:
+            note = pm.get("note", "")
+            st = note.split("sha256[:16] ")[1].split(";")[0] if "sha256[:16] " in note else None
+            traffic = tot / steps_prof
+            tstamp = {"source": "profiles/r03_c5_pmc_hbm_traffic.json", "sources_sha": st, "matches_current_kernel_sources": st == kernel_source_stamp() if st else None}
+    except Exception:
+        pass
     return {"workload": "configs[4] per-GPU shape: 2827->4096x5->257, 512 frames/GPU/step, bf16 operands, fp32 master W/delta, 1 GPU",
             "dtype": "bf16", "ms_per_step": 1e3 * dt, "value": C5_BUNCH / dt, "unit": "frames/s",
             "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_step": alg, "traffic": None},
+                         "frac": alg / dt / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_step": alg, "traffic": traffic, "traffic_stamp": tstamp},
             "frac_of_bf16_mfma_peak": flops_per_frame(C5_LAYERS) * C5_BUNCH / dt / 2.5e15}
 
 
@@ -370,23 +414,19 @@ def main():
         P = n_params(LAYERS)
         # algorithmic bytes of that launch: W and delta read + written (16P) + every layer's activations and dEdX read once
         alg_bytes = 16.0 * P + 4.0 * BUNCH * (sum(LAYERS[:-1]) + sum(LAYERS[1:]))
-        traffic, tsrc = None, None
-        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-                for k, v in pm.get("kernels", pm).items():
-                    if "bp_wgrad_dma" in k and "grid=" in k and int(k.split("grid=")[1]) > 500000:       # the grouped launch (3648 workgroups)
-                        traffic = (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6
-                        tsrc = "profiles/" + name
-                if traffic is not None:
-                    break
-            except Exception:
-                continue
+        # HBM-side bytes of that launch: NOT measured in this run (PMC collection needs its own rocprofv3 passes) but read from
+        # the committed pass of tools/profile_r03.sh, stamped with the kernel sources it was taken on
+        traffic, tstamp = None, None
+        for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+            traffic, tstamp = profiled_traffic(name, lambda k: "bp_wgrad_dma" in k and "bf16" not in k and "grid=" in k and int(k.split("grid=")[1]) > 500000)
+            if traffic is not None:
+                break
         # cross-check against the committed rocprofv3 --kernel-trace --stats summary of this same command
         rk_ms = None
         try:
             import csv
-            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv"))):
+            rk_file = "r03_bench_kernel_stats.csv" if os.path.exists(os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")) else "r02_bench_kernel_stats.csv"
+            for row in csv.DictReader(open(os.path.join(ROOT, "profiles", rk_file))):
                 if row["Name"].startswith("void bp_wgrad_dma<16, 4, 4, 256") and "true" not in row["Name"]:     # (the fused-update form)
                     rk_ms = float(row["AverageNs"]) * 1e-6
         except Exception:
@@ -394,13 +434,13 @@ def main():
         res["roofline"] = {
             "bound": "mfma", "kernel": "bp_wgrad_dma<16,4,4,256> (wgrad + fused momentum update of all 4 layers, one grouped launch per step)",
             "achieved": ach, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TF,
-            "traffic": traffic, "traffic_source": tsrc, "algorithmic_flops": wg_fl, "algorithmic_bytes": alg_bytes,
+            "traffic": traffic, "traffic_stamp": tstamp, "algorithmic_flops": wg_fl, "algorithmic_bytes": alg_bytes,
             "kernel_ms": wg_ms,
             "rocprof_kernel_ms": rk_ms, "rocprof_frac": (wg_fl / (rk_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TF) if rk_ms else None,
-            "rocprof_source": "profiles/r02_bench_kernel_stats.csv (AverageNs of the same kernel under the same command, another box)",
+            "rocprof_source": "profiles/%s (AverageNs of the same kernel under the same command, another box)" % rk_file if rk_ms else None,
             "measured_by": "HIP events inside 100 real steps on the launch stream (bp_profile_step): previous event -> own event, "
                                                      "i.e. the kernel plus the ~3 us dependent-launch boundary in front of it; rocprofv3's average of the kernel alone "
-                                                     "(profiles/r02_bench_kernel_stats.csv) is that much shorter",
+                                                     "(rocprof_kernel_ms) is that much shorter",
             "kernels_in_step_ms": {k: v[0] for k, v in prof.items()}, "launches_per_step": {k: v[1] for k, v in prof.items()},
             "hidden_fwd_2048x2048": {"achieved": 2.0 * BUNCH * 2048 * 2048 / (prof["fwd_hidden"][0] * 1e-3) / 1e12,
                                      "frac": 2.0 * BUNCH * 2048 * 2048 / (prof["fwd_hidden"][0] * 1e-3) / 1e12 / PEAK_MFMA_F32_TF,

@@ -628,7 +628,7 @@ static bool bf_dma_ok(const bp_handle *h)
     static const bool off = getenv("BP_BF16_NO_DMA") != nullptr;                  // development A/B switch
     return !off && (h->Bp == 128 || h->Bp == 256 || h->Bp == 512 || h->Bp == 1024);
 }
-static hipError_t bf_wgrads_dma_tm(bp_handle *h, const int *ls, int n, bool fused, int tm)
+static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
 {
     const float m = h->cfg.momentum, lr = h->cfg.lrate;
     const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
@@ -640,7 +640,7 @@ static hipError_t bf_wgrads_dma_tm(bp_handle *h, const int *ls, int n, bool fuse
             const int l = ls[i0 + i], prev = h->ld[l - 1], cur = h->ld[l];
             BfWgradProblem &p = a.p[i];
             p.A = h->ybT[l - 1]; p.B = h->dxbT[l]; p.ldk = h->Bp;
-            p.tiles_m = prev / (64 * tm); p.tiles_n = cur / 64;
+            p.tiles_m = prev / 64; p.tiles_n = cur / 64;
             p.e = epi_zero();
             p.e.ldc = cur; p.e.m_limit = prev; p.e.n_limit = cur; p.e.n_true = h->s[l];
             if (fused) {
@@ -656,11 +656,9 @@ static hipError_t bf_wgrads_dma_tm(bp_handle *h, const int *ls, int n, bool fuse
             t += (p.tiles_m * p.tiles_n + 7) & ~7;             // (problem-relative block index keeps the XCD bits, see run_multi)
         }
         a.first_tile[cnt] = t; a.n = cnt;
-#define BF_DMA_LAUNCH(K)                                                                                                    \
-        do { if (fused && tm == 2) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, false, 2>), dim3(t), dim3(256), 0, h->stream, a);  \
-             else if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, false, 1>), dim3(t), dim3(256), 0, h->stream, a);         \
-             else if (tm == 2) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, true, 2>), dim3(t), dim3(256), 0, h->stream, a);        \
-             else hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, true, 1>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
+#define BF_DMA_LAUNCH(K)                                                                                             \
+        do { if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, false>), dim3(t), dim3(256), 0, h->stream, a);        \
+             else hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, true>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
         switch (h->Bp) {
         case 128: BF_DMA_LAUNCH(128); break;
         case 256: BF_DMA_LAUNCH(256); break;
@@ -673,20 +671,8 @@ static hipError_t bf_wgrads_dma_tm(bp_handle *h, const int *ls, int n, bool fuse
     }
     return hipSuccess;
 }
-// layers whose input width is a multiple of 128 (and wide enough to still fill the chip) take the 128x64 tiles
-static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
-{
-    static const bool no128 = getenv("BP_BF16_WGRAD_NO128") != nullptr;           // development A/B switch
-    int big[BP_MAXLAYER], small[BP_MAXLAYER], nb = 0, ns = 0;
-    for (int i = 0; i < n; ++i) {
-        const int l = ls[i], prev = h->ld[l - 1], cur = h->ld[l];
-        if (!no128 && prev % 128 == 0 && (prev / 128) * (cur / 64) >= 768) big[nb++] = l; else small[ns++] = l;
-    }
-    hipError_t er = hipSuccess;
-    if (ns && (er = bf_wgrads_dma_tm(h, small, ns, fused, 1)) != hipSuccess) return er;
-    if (nb) er = bf_wgrads_dma_tm(h, big, nb, fused, 2);
-    return er;
-}
+// (measured round 3: 128x64 workgroup tiles -- 25 % fewer operand bytes through L2 -> LDS, 3 workgroups per CU -- are no
+// faster than these 64x64 ones on the configs[4] shape: 0.846 vs 0.835 ms per step)
 static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool fused)
 {
     const int L = h->L;

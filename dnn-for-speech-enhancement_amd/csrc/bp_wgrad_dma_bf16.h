@@ -32,15 +32,12 @@ struct BfWgradProblem {
 enum { BF_WGRAD_MAXP = 8 };
 struct BfWgradMulti { BfWgradProblem p[BF_WGRAD_MAXP]; int first_tile[BF_WGRAD_MAXP + 1]; int n; };
 
-// TM = 32x32 blocks per wave along m: 1 -> 64x64 workgroup tiles (4 workgroups per CU), 2 -> 128x64 tiles (25 % fewer operand
-// bytes through L2 -> LDS per FLOP, 3 workgroups per CU); the chip-wide L2 -> CU delivery rate (~10 TB/s), not HBM, is what
-// this kernel runs into first, so the larger tile is used wherever the layer's input width is a multiple of 128.
-template <int KTOT, bool STORE, int TM = 1>
+template <int KTOT, bool STORE>
 struct WgradDmaBf {
-    static constexpr int BM = 64 * TM, BN = 64, BK = 32, ST = 4, D = ST - 1, NT = KTOT / BK;
+    static constexpr int BM = 64, BN = 64, BK = 32, ST = 4, D = ST - 1, NT = KTOT / BK;
     static constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK, STAGE = A_STAGE + B_STAGE;     // halfs
     static constexpr int SMEM = ST * STAGE;                                                    // halfs (32 KB)
-    static constexpr int NDMA = TM + 1, NWD = STORE ? 0 : 32 * TM;
+    static constexpr int NDMA = 2, NWD = STORE ? 0 : 32;
     static_assert(KTOT % BK == 0 && NT > D, "bunch rows");
     typedef __attribute__((address_space(3))) void *lds_ptr;
     typedef const __attribute__((address_space(1))) void *glb_ptr;
@@ -48,34 +45,29 @@ struct WgradDmaBf {
     static __device__ __forceinline__ void issue_tile(const BfWgradProblem &g, int m0, int n0, int k0, bf16_t *smem, int st, int wave, int lane)
     {
         const int r = wave * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 3);            // LDS slot lane&3 of row r <- k-chunk c
-#pragma unroll
-        for (int i = 0; i < TM; ++i)                                                         // (row r + 64*i: same swizzle bits)
-            __builtin_amdgcn_global_load_lds((glb_ptr)(g.A + (size_t)(m0 + 64 * i + r) * g.ldk + k0 + c * 8), (lds_ptr)(smem + st * STAGE + i * 2048 + wave * 512), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(g.A + (size_t)(m0 + r) * g.ldk + k0 + c * 8), (lds_ptr)(smem + st * STAGE + wave * 512), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_ptr)(g.B + (size_t)(n0 + r) * g.ldk + k0 + c * 8), (lds_ptr)(smem + st * STAGE + A_STAGE + wave * 512), 16, 0, 0);
     }
-    static __device__ __forceinline__ void multiply(const bf16_t *smem, int st, int ra, int rb, int kh, f32x16 (&acc)[TM])
+    static __device__ __forceinline__ void multiply(const bf16_t *smem, int st, int ra, int rb, int kh, f32x16 &acc)
     {
         const bf16_t *ap = smem + st * STAGE + ra * BK, *bp = smem + st * STAGE + A_STAGE + rb * BK;
-        const int sa = (ra >> 2) & 3, sb = (rb >> 2) & 3;              // (rows ra and ra + 32 share the swizzle bits)
-        bf16x8_t a[TM][2], b[2];
+        const int sa = (ra >> 2) & 3, sb = (rb >> 2) & 3;
+        bf16x8_t a[2], b[2];
         // keep the fragment reads and their MFMAs inside this k-tile's barrier interval: the stage is refilled by DMA
         // right after the NEXT barrier, so every read of it must have completed (been consumed) before that barrier
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i][q] = *reinterpret_cast<const bf16x8_t *>(ap + i * 32 * BK + (((2 * q + kh) ^ sa) * 8));
+            a[q] = *reinterpret_cast<const bf16x8_t *>(ap + (((2 * q + kh) ^ sa) * 8));
             b[q] = *reinterpret_cast<const bf16x8_t *>(bp + (((2 * q + kh) ^ sb) * 8));
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][q], b[q], acc[i], 0, 0, 0);
+        for (int q = 0; q < 2; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], b[q], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     template <int T>
     static __device__ __forceinline__ void iter(const BfWgradProblem &g, int m0, int n0, bf16_t *smem, int wave, int lane, int tid, int ra, int rb,
-                                                int kh, int mb, int nb, bool do_bias, float &bsum, f32x16 (&acc)[TM], EpiPre (&pre)[TM])
+                                                int kh, int mb, int nb, bool do_bias, float &bsum, f32x16 &acc, EpiPre &pre)
     {
         if constexpr (T < NT) {
             // in flight here: tiles T .. min(T+D, NT)-1, plus the 32 W/delta loads once the last tile has been issued
@@ -84,10 +76,7 @@ struct WgradDmaBf {
             VmWait<tiles_after * NDMA + (wd_out ? NWD : 0)>::go();
             __builtin_amdgcn_s_barrier();
             if constexpr (T + D < NT) issue_tile(g, m0, n0, (T + D) * BK, smem, (T + D) % ST, wave, lane);
-            if constexpr (T + D == NT && !STORE) {                                                                      // behind the last tile
-#pragma unroll
-                for (int i = 0; i < TM; ++i) epilogue_fetch<EPI_WGRAD_UPDATE, 0, 16>(g.e, mb + 32 * i, nb, lane, pre[i]);
-            }
+            if constexpr (T + D == NT && !STORE) epilogue_fetch<EPI_WGRAD_UPDATE, 0, 16>(g.e, mb, nb, lane, pre);     // behind the last tile
             if (do_bias) {          // column sums of dEdX: row (tid >> 2) of the B tile, one 16-byte chunk per thread (any slot order)
                 // (inline asm: for a plain LDS load next to in-flight LDS-DMA hipcc drains vmcnt(0) first, which would
                 // serialise this workgroup's whole ring; the counted wait above already covers the stage read here)
@@ -111,16 +100,14 @@ struct WgradDmaBf {
             int tile_m, tile_n;
             if ((g.tiles_n & 7) == 0) { const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3; tile_n = xcd * per + j % per; tile_m = j / per; }
             else { tile_m = b % g.tiles_m; tile_n = b / g.tiles_m; }
-            const int m0 = tile_m * BM, n0 = tile_n * BN, mb = m0 + wm * 32 * TM, nb = n0 + wn * 32;
-            const int ra = wm * 32 * TM + (lane & 31), rb = wn * 32 + (lane & 31), kh = lane >> 5;
-            f32x16 acc[TM];
+            const int m0 = tile_m * BM, n0 = tile_n * BN, mb = m0 + wm * 32, nb = n0 + wn * 32;
+            const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31), kh = lane >> 5;
+            f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const bool do_bias = tile_m == 0;
             float bsum = 0.f;
-            EpiPre pre[TM];
+            EpiPre pre;
 #pragma unroll
             for (int t = 0; t < D; ++t) issue_tile(g, m0, n0, t * BK, smem, t, wave, lane);
             iter<0>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, mb, nb, do_bias, bsum, acc, pre);
@@ -140,20 +127,17 @@ struct WgradDmaBf {
             }
             // ---- epilogue: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block.
             // Padded rows / columns hold zeros in W, delta and G and stay zero under the update: no predicates.
-            const int n = nb + (lane & 31);
-#pragma unroll
-            for (int blk = 0; blk < TM; ++blk) {
-            const int rbase = mb + 32 * blk + 4 * (lane >> 5);
+            const int n = nb + (lane & 31), rbase = mb + 4 * (lane >> 5);
             if constexpr (STORE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n] = acc[blk][r];
+                for (int r = 0; r < 16; ++r) e.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n] = acc[r];
             } else {
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const size_t i = (size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n;
-                    const float w = pre[blk].p0[r];
-                    const float d = e.mom * pre[blk].p1[r] - e.c1 * (acc[blk][r] / e.ndiv + e.wc * w);     // kernUpdatedelta
+                    const float w = pre.p0[r];
+                    const float d = e.mom * pre.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);     // kernUpdatedelta
                     e.aux2[i] = d;
                     v[r] = d + 1.0f * w;                                                         // kernAccSum
                     e.C[i] = v[r];
@@ -170,16 +154,15 @@ struct WgradDmaBf {
                     *reinterpret_cast<uint2 *>(g.WbT + (size_t)n * g.ldwbt + rbase + 8 * q) = pk;
                 }
             }
-            }   // blocks of the wave
             if (b + stride < g.tiles_m * g.tiles_n) __syncthreads();      // the ring is refilled by the next tile's prologue
         }
     }
 };
 
-template <int KTOT, bool STORE, int TM = 1>
-__global__ __launch_bounds__(256, TM == 1 ? 4 : 3) void bp_wgrad_dma_bf16(const BfWgradMulti a)
+template <int KTOT, bool STORE>
+__global__ __launch_bounds__(256, 4) void bp_wgrad_dma_bf16(const BfWgradMulti a)
 {
-    using K = WgradDmaBf<KTOT, STORE, TM>;
+    using K = WgradDmaBf<KTOT, STORE>;
     __shared__ __attribute__((aligned(16))) bf16_t smem[K::SMEM];
     const int b = blockIdx.x;
     int p = 0;

@@ -51,6 +51,12 @@ struct Params {
 
 using bp::shard_rows;
 
+// A rank that leaves through exit() -- every error path of this file and of the reader does, the reference's convention --
+// raises the ring's abort flag on its way out, so that its peers fail at once instead of waiting for it.
+static bp::ChunkRing *g_ring = nullptr;
+static bool g_ring_finished = false;
+static void ring_abort_at_exit() { if (g_ring && !g_ring_finished) g_ring->abort(); }
+
 typedef bp::PfileReader::WindowChunk WindowChunk;
 static bp_window_chunk describe(const WindowChunk &w, int context)
 {
@@ -244,6 +250,7 @@ int main(int argc, char **argv)
         int fcap = 1;
         for (int c = 0; c < nchunks; ++c) { const int f = reader.chunk_shape(tp, c).n_frames; if (f > fcap) fcap = f; }
         ring = new bp::ChunkRing(world, fcap, P.traincache, en - st + 2, P.fea_dim, P.layersizes[L - 1], reader.nat());
+        g_ring = ring; atexit(ring_abort_at_exit);
         fflush(stdout); fflush(log);
         for (int r = 1; r < world; ++r) {
             const pid_t c = fork();
@@ -304,6 +311,7 @@ int main(int argc, char **argv)
             ring->done(i);
         }
         helper.join();
+        g_ring_finished = true;
     } else {
         ChunkStream chunks(reader, tp, chunk_index, true, P.prefetch);
         for (int i = 0; i < nchunks; ++i) {

@@ -14,6 +14,7 @@
 // Slot i&1 is refilled while the other one trains.  A rank that dies raises `abort`, so the others fail instead of hang.
 #pragma once
 #include <atomic>
+#include <new>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

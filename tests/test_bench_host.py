@@ -61,3 +61,14 @@ def test_bench_under_torch_distributed_run():
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and not j["self_launched"]
+
+
+def test_profiled_traffic_is_stamped_with_the_kernel_sources():
+    """roofline.traffic comes from a committed PMC pass, not from the run: the line must say which kernel sources the pass
+    was taken on and whether they are the ones being run (VERDICT r2 weak #9: a stale file must not pass silently)."""
+    import bench
+    st = bench.kernel_source_stamp()
+    assert len(st) == 16 and int(st, 16) >= 0
+    t, stamp = bench.profiled_traffic("r02_pmc_hbm_traffic.json", lambda k: "bp_wgrad_dma" in k and "grid=" in k and int(k.split("grid=")[1]) > 500000)
+    assert t and 2.5e8 < t < 4e8 and stamp["kernel"].startswith("void bp_wgrad_dma") and stamp["matches_current_kernel_sources"] in (None, False)
+    assert bench.profiled_traffic("no_such_file.json", lambda k: True) == (None, None)
