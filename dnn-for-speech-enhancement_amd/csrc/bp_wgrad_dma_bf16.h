@@ -132,26 +132,41 @@ struct WgradDmaBf {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) e.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n] = acc[r];
             } else {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const size_t i = (size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n;
-                    const float w = pre.p0[r];
-                    const float d = e.mom * pre.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);     // kernUpdatedelta
-                    e.aux2[i] = d;
-                    v[r] = d + 1.0f * w;                                                         // kernAccSum
-                    e.C[i] = v[r];
-                }
+                // The two bf16 shadows leave through LDS so that they reach memory as FULL 128-byte lines: written straight
+                // from the accumulator layout they are 64-byte (Wb) and 16-byte (WbT) pieces of lines, and cost 112 us of an
+                // 813 us configs[4] step for 14 % of its bytes (measured by leaving them out, round 3).  The operand ring is
+                // free once every wave has passed its last multiply: sWb [64 m][72], sWbT [64 n][72] halfs (144-byte rows).
+                constexpr int LDSH = 72;
+                bf16_t *sWb = smem, *sWbT = smem + 64 * LDSH;
+                __syncthreads();
+                const int ml = wm * 32 + 4 * (lane >> 5), nl = wn * 32 + (lane & 31);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bf16_t hb[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        hb[j] = f2bf(v[4 * q + j]);
-                        g.Wb[(size_t)(rbase + 8 * q + j) * g.ldwb + n] = hb[j];
+                        const int r = 4 * q + j;
+                        const size_t i = (size_t)(rbase + 8 * q + j) * e.ldc + n;
+                        const float w = pre.p0[r];
+                        const float d = e.mom * pre.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);     // kernUpdatedelta
+                        e.aux2[i] = d;
+                        const float wnew = d + 1.0f * w;                                             // kernAccSum
+                        e.C[i] = wnew;
+                        hb[j] = f2bf(wnew);
+                        sWb[(ml + 8 * q + j) * LDSH + nl] = hb[j];
                     }
-                    const uint2 pk = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
-                    *reinterpret_cast<uint2 *>(g.WbT + (size_t)n * g.ldwbt + rbase + 8 * q) = pk;
+                    *reinterpret_cast<uint2 *>(sWbT + nl * LDSH + ml + 8 * q) =
+                        make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+                }
+                __syncthreads();
+                // 8 threads per 128-byte row, 32 rows per pass: Wb rows m0.., WbT rows n0..
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = (tid >> 3) + 32 * i, ch = (tid & 7) * 8;
+                    const uint4 a4 = *reinterpret_cast<const uint4 *>(sWb + row * LDSH + ch);
+                    const uint4 b4 = *reinterpret_cast<const uint4 *>(sWbT + row * LDSH + ch);
+                    *reinterpret_cast<uint4 *>(g.Wb + (size_t)(m0 + row) * g.ldwb + n0 + ch) = a4;
+                    *reinterpret_cast<uint4 *>(g.WbT + (size_t)(n0 + row) * g.ldwbt + m0 + ch) = b4;
                 }
             }
             if (b + stride < g.tiles_m * g.tiles_n) __syncthreads();      // the ring is refilled by the next tile's prologue
