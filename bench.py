@@ -188,8 +188,8 @@ def c5_line(dnnse_amd, dev, steps=40):
         for k, v in pm["kernels"].items():
             if k.startswith(("void bp_gemm_bf16", "void bp_wgrad_dma_bf16", "bp_bias_bf16", "bp_to_bf16_both")) and "fetch_MB_corrected_x2" in v and "write_MB" in v:
                 tot += (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6 * v["launches"]
-                if k.startswith("void bp_wgrad_dma_bf16") and "false, 2" in k:
-                    steps_prof = v["launches"]                     # one launch of the large-tile group per step
+                if k.startswith("void bp_wgrad_dma_bf16") and "false" in k:
+                    steps_prof = v["launches"]                     # ONE grouped wgrad launch per step
         if steps_prof:
             note = pm.get("note", "")
             st = note.split("sha256[:16] ")[1].split(";")[0] if "sha256[:16] " in note else None
