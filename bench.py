@@ -330,8 +330,18 @@ def main():
         kw.update(global_bunchsize=BUNCH * world, rank_frame_offset=rank * BUNCH)
     g = dnnse_amd.BP_GPU(world, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, **kw)
     rank_table = None
+    exchange_used, exchange_note = args.exchange, None
     if dp:
-        g.dp_attach(world, rank, key, transport=1 if args.exchange == "rccl" else 0)
+        try:
+            g.dp_attach(world, rank, key, transport=1 if args.exchange == "rccl" else 0)
+        except dnnse_amd.BPError as e:
+            # The native exchange checks its memory-model assumptions on the group's real devices at attach and refuses to
+            # run when they do not hold (every rank sees the same verdict: it is all-gathered).  Rather than produce no
+            # number, fall back to the RCCL transport of the same step and say so in the line.
+            if args.exchange != "native" or world == 1:
+                raise
+            exchange_used, exchange_note = "rccl", "native attach failed (%s); fell back to the RCCL transport" % str(e)[:200]
+            g.dp_attach(world, rank, key + "-rccl", transport=1)
         # what each rank attached to, as the library saw it: a reader can check N ranks on N devices
         rank_table = []
         for p in range(world):
@@ -388,7 +398,7 @@ def main():
                                "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
                                % (BUNCH, BUNCH * world, chunk),
                    "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world,
-                   "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if args.exchange == "rccl" else
+                   "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if exchange_used == "rccl" else
                                  "in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)") if dp else "none"),
                    "launcher": "self (bench.py forked its ranks)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else
                                ("torch.distributed.run" if world > 1 else "single process")},
@@ -397,6 +407,8 @@ def main():
         res["ranks"] = rank_table
         res["distinct_devices"] = len(set(r["pci_bus_id"] for r in rank_table))
         res["dp_acquire_mode"] = g.dp_peer_info(0)[3]
+        if exchange_note:
+            res["exchange_note"] = exchange_note
     if rank == 0:
         res["step_frac_of_mfma_peak"] = flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF
     if dp:
