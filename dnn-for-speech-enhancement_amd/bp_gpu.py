@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "bp_grad_layout", "bp_grad_floats", "bp_read_grads", "bp_read_layer_output", "bp_last_train_ms", "bp_time_kernel",
     "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
     "bp_set_hyper", "bp_dp_attach", "bp_dp_attach_ex", "bp_dp_detach", "bp_dp_info", "bp_dp_peer_info", "bp_dp_barrier", "bp_dp_allgather",
-    "bp_rdv_open", "bp_rdv_barrier", "bp_rdv_allgather", "bp_rdv_close", "bp_device_pci_bus_id",
+    "bp_rdv_open", "bp_rdv_barrier", "bp_rdv_allgather", "bp_rdv_close", "bp_device_pci_bus_id", "bp_host_register", "bp_host_unregister",
     "bp_profile_step", "bp_measure_peaks", "bp_device_count", "bp_train_resident_masked", "bp_forward_windows",
 ]
 PROF_KINDS = ["fwd_l1", "fwd_hidden", "fwd_out", "dgrad_out", "dgrad_hidden", "wgrad_update_grouped"]
@@ -118,6 +118,8 @@ def load_library(path=None):
     lib.bp_rdv_close.argtypes = [C.c_void_p]
     lib.bp_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     lib.bp_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.bp_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.bp_host_unregister.argtypes = [C.c_void_p]
     lib.bp_read_layer_output.argtypes = [hp, C.c_int, fp, C.c_size_t]
     lib.bp_dp_detach.argtypes = [hp]
     lib.bp_dp_info.argtypes = [hp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint)]

@@ -1053,6 +1053,22 @@ extern "C" int bp_rdv_allgather(bp_rdv *r, const void *mine, size_t bytes, void 
 }
 extern "C" int bp_rdv_close(bp_rdv *r) { rdv_close(r, false); return BP_OK; }
 
+// Pin caller-owned host memory (hipHostRegister): uploads from it are then true DMA transfers on the copy engines instead
+// of staged copies through the runtime's bounce buffers (the reference stages its uploads through pinned memory too,
+// devnew_vf / cublasSetVectorAsync, BP_GPU.cu:926-992).  Optional: every upload entry point accepts pageable memory.
+extern "C" int bp_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes) return fail(BP_ERR_ARG, "bp_host_register: null argument");
+    HIPCHK(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return BP_OK;
+}
+extern "C" int bp_host_unregister(void *p)
+{
+    if (!p) return fail(BP_ERR_ARG, "bp_host_unregister: null argument");
+    HIPCHK(hipHostUnregister(p));
+    return BP_OK;
+}
+
 extern "C" int bp_device_pci_bus_id(int device, char *buf, int len)
 {
     if (!buf || len < 16) return fail(BP_ERR_ARG, "bp_device_pci_bus_id: buffer of at least 16 bytes needed");

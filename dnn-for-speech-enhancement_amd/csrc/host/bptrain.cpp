@@ -74,7 +74,24 @@ static bp_window_chunk describe(const WindowChunk &w, int context)
 class ChunkStream {
 public:
     ChunkStream(bp::PfileReader &r, const bp::PfileReader::Plan &p, const std::vector<int> &order, bool shuffle, bool prefetch)
-        : r_(r), p_(p), order_(order), shuffle_(shuffle), prefetch_(prefetch) { if (prefetch_ && !order_.empty()) start(0); }
+        : r_(r), p_(p), order_(order), shuffle_(shuffle), prefetch_(prefetch)
+    {
+        // both slots get their final capacity now and are pinned (bp_host_register): the uploads of bp_*_windows are then DMA
+        // transfers on the copy engines, not staged pageable copies that compete with the training kernels for the CUs
+        size_t fcap = 0;
+        for (size_t c = 0; c < p.chunk_frame_st.size(); ++c) { const size_t f = (size_t)r.chunk_shape(p, (int)c).n_frames; if (f > fcap) fcap = f; }
+        for (auto &s : slot_) {
+            s.fea.reserve(fcap * r.fea_dim()); s.targ.reserve(fcap * r.out_dim());
+            if (fcap && bp_host_register(s.fea.data(), s.fea.capacity() * sizeof(float)) == 0) pinned_.push_back(s.fea.data());
+            if (fcap && bp_host_register(s.targ.data(), s.targ.capacity() * sizeof(float)) == 0) pinned_.push_back(s.targ.data());
+        }
+        if (prefetch_ && !order_.empty()) start(0);
+    }
+    ~ChunkStream()
+    {
+        if (fut_.valid()) fut_.wait();
+        for (void *q : pinned_) bp_host_unregister(q);
+    }
     const WindowChunk &get(int i)
     {
         if (prefetch_) {
@@ -92,6 +109,7 @@ private:
     }
     bp::PfileReader &r_; const bp::PfileReader::Plan &p_; std::vector<int> order_; bool shuffle_, prefetch_;
     WindowChunk slot_[2];
+    std::vector<void *> pinned_;
     std::future<void> fut_;
 };
 
@@ -285,6 +303,7 @@ int main(int argc, char **argv)
         // (rank 0: tables + shuffle + noise-aware rows; everyone: 1/world of the frame conversion), the main thread
         // consumes: this rank's rows of every global minibatch
         if (!P.stack_on_device && lead) fprintf(log, "(gpu_used > 1: stack=host is not used, the context windows are built on the device)\n");
+        const bool ring_pinned = bp_host_register(ring->base(), ring->bytes()) == 0;      // (per process: after the fork)
         std::thread helper([&] {
             for (int i = 0; i < nchunks; ++i)
                 if (!ring->produce(reader, tp, i, chunk_index[i], true, rank)) return;
@@ -312,6 +331,7 @@ int main(int argc, char **argv)
         }
         helper.join();
         g_ring_finished = true;
+        if (ring_pinned) bp_host_unregister(ring->base());
     } else {
         ChunkStream chunks(reader, tp, chunk_index, true, P.prefetch);
         for (int i = 0; i < nchunks; ++i) {

@@ -108,6 +108,8 @@ public:
         return true;
     }
     void done(int seq) { hdr_->slot[seq & 1].consumed.fetch_add(1); }
+    void *base() const { return base_; }        // the whole mapping, e.g. to pin it for DMA uploads (after the fork, per process)
+    size_t bytes() const { return bytes_; }
 
 private:
     struct Slot { std::atomic<int> tables_seq, converted, ready_seq, consumed; int n_samples, n_frames, n_nat; };

@@ -231,6 +231,12 @@ int bp_rdv_open(const char *key, int world, int rank, double timeout_s, bp_rdv *
 int bp_rdv_barrier(bp_rdv *r);
 int bp_rdv_allgather(bp_rdv *r, const void *mine, size_t bytes, void *all);   /* bytes <= 64 */
 int bp_rdv_close(bp_rdv *r);
+/* Pin / unpin caller-owned host memory (hipHostRegister) so that uploads from it (bp_train_chunk[_windows], bp_upload_*)
+ * are DMA transfers instead of staged pageable copies; optional -- every entry point accepts pageable memory, which is what
+ * the reference's callers have (`new[]`, Interface.cc:401-403; the reference stages through pinned memory itself,
+ * BP_GPU.cu:926-992).  For hosts that do not link the HIP runtime. */
+int bp_host_register(void *p, size_t bytes);
+int bp_host_unregister(void *p);
 /* PCI bus id of a visible device (hipDeviceGetPCIBusId), for hosts that do not link the HIP runtime. */
 int bp_device_pci_bus_id(int device, char *buf, int len);
 
