@@ -147,6 +147,40 @@ def test_one_reader_per_node_ring_equals_the_single_reader(tmp_path, dump_exe, w
         assert o == rr.size
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_inference_planner_random_geometries(tmp_path, dump_exe, seed):
+    """Randomised sentence lengths, context and cache sizes (sentences shorter than the context, longer than the cache, cache
+    smaller than one window run): plan_inference still emits every window exactly once, bit-identical to the restatement."""
+    rs = np.random.default_rng(100 + seed)
+    D, ctx = int(rs.integers(3, 9)), int(rs.integers(1, 7))
+    cache = int(rs.integers(ctx + 1, 40))
+    nat = bool(rs.integers(0, 2))
+    lens = [int(v) for v in rs.integers(1, 70, size=int(rs.integers(3, 12)))]
+    lens = [ln if ln >= 6 or ln < ctx else 6 for ln in lens]      # (NAT of a sentence with ctx <= len < 6 reads past it: reference quirk, not pinned here)
+    if not any(ln >= ctx for ln in lens):
+        lens[0] = ctx + 3
+    n = sum(lens)
+    fea = rs.normal(size=(n, D)).astype(np.float32)
+    mean = rs.normal(size=D).astype(np.float32)
+    istd = (0.5 + rs.random(size=D)).astype(np.float32)
+    fp, npth, out = (str(tmp_path / x) for x in ("f.pfile", "n.norm", "o.bin"))
+    PU.write_pfile(fp, lens, fea); PU.write_norm(npth, mean, istd)
+    s0 = D * (ctx + 1) if nat else D * ctx
+    subprocess.check_call([dump_exe, "infer", fp, npth, str(D), str(ctx), "0", str(cache), str(s0), "0", str(len(lens) - 1), out, "x", "x"])
+    raw = np.fromfile(out, np.uint8)
+    nch, ts = np.frombuffer(raw, np.int32, 2, 0)
+    o, got = 8, []
+    for _ in range(nch):
+        cnt, _st = np.frombuffer(raw, np.int32, 2, o); o += 8
+        assert 0 <= cnt <= cache
+        got.append(np.frombuffer(raw, np.float32, cnt * s0, o).reshape(cnt, s0)); o += 4 * cnt * s0
+    got = np.concatenate(got)
+    mean_t = np.array([float("%.9g" % v) for v in mean], np.float32)
+    istd_t = np.array([float("%.9g" % v) for v in istd], np.float32)
+    exp = PU.expected_windows(fea, lens, mean_t, istd_t, ctx, nat)
+    assert ts == exp.shape[0] == got.shape[0] and np.array_equal(got, exp), (D, ctx, cache, nat, lens)
+
+
 def test_weight_file_bytes_and_roundtrip(tmp_path, dump_exe):
     ls = [6, 4, 3]
     rs = np.random.default_rng(1)
