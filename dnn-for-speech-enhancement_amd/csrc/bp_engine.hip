@@ -69,16 +69,23 @@ struct bp_handle {
     uint32_t th_vis, th_hid;
     hipEvent_t ev0, ev1; float last_ms; int last_bunches;
     std::vector<void *> allocs;
-    // grow-only device staging of a window chunk (bp_upload_chunk_windows): raw frames, raw targets, NAT rows, tables
-    struct Raw { void *p; size_t bytes; } raw[4];
     // Upload path: host->device copies run on copy_stream so that chunk i+1 is uploaded while chunk i trains.
-    // Stacked chunks alternate between two device buffers (in/targ and in_alt/targ_alt, the second pair allocated
-    // on first use); window chunks go through the raw staging above and are expanded into `in` in stream order.
+    // STACKED chunks (bp_upload_chunk: the caller hands [frames][layersizes[0]] rows, the reference's interface) alternate
+    // between two device buffer pairs (in/targ and in_alt/targ_alt; allocated on first use).
+    // WINDOW chunks (bp_upload_chunk_windows: raw frames + index tables) stay as they are uploaded -- two
+    // grow-only staging sets alternate the same way -- and every bunch stacks ITS rows into the tile x0s/tgs right
+    // before its forward (bp_stage_bunch): no stacked chunk, no masked copy of it.
+    struct Raw { void *p; size_t bytes; };
+    struct WinSet { Raw r[4]; } wset[2];      // raw frames, raw target frames, NAT rows, tables (win_start | targ_frame | nat_row)
+    int wcur;                                 // staging set of the resident window chunk
+    bool windows;                             // the resident chunk is a window chunk
+    struct { const float *fea, *tg, *nat; const int *ws, *tf, *nr; int D, win; } wv;   // views of set wcur
+    float *x0s, *tgs;                         // [Bp][ld_0], [Bp][ld_L]: the staged bunch
     hipStream_t copy_stream;
     hipEvent_t ev_copy;            // copy_stream: this chunk's H2D copies are done
-    hipEvent_t ev_retired;         // main stream: the buffer pair that is NOT current is no longer read
-    hipEvent_t ev_staging;         // main stream: the raw staging has been expanded
-    bool retired_valid, staging_valid;
+    hipEvent_t ev_retired;         // main stream: the stacked buffer pair that is NOT current is no longer read
+    hipEvent_t ev_wretired;        // main stream: the window staging set that is NOT current is no longer read
+    bool retired_valid, wretired_valid;
     float *in_alt, *targ_alt;
     // compute_dtype == 1 (bp_bf16.h): bf16 copies, each in both orientations
     bool bf;
@@ -148,11 +155,11 @@ extern "C" int bp_destroy(bp_handle *h)
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     if (h->dp) (void)bp_dp_detach(h);
     for (void *p : h->allocs) (void)hipFree(p);
-    for (auto &r : h->raw) if (r.p) (void)hipFree(r.p);
+    for (auto &ws : h->wset) for (auto &r : ws.r) if (r.p) (void)hipFree(r.p);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
     if (h->ev_retired) (void)hipEventDestroy(h->ev_retired);
-    if (h->ev_staging) (void)hipEventDestroy(h->ev_staging);
+    if (h->ev_wretired) (void)hipEventDestroy(h->ev_wretired);
     if (h->host_out) (void)hipHostFree(h->host_out);
     if (h->out_chunk) (void)hipFree(h->out_chunk);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -165,6 +172,8 @@ extern "C" int bp_destroy(bp_handle *h)
 static int dp_check(bp_handle *h);
 static int check_hyper(float, float, float, int, float, float, const char *);
 static hipError_t dp_bunch(bp_handle *h, int first);
+static int ensure_stacked(bp_handle *h);
+static hipError_t stage_bunch(bp_handle *h, int first, int rows, bool train);
 static hipError_t dp_flush(bp_handle *h);
 static int dp_gather_deltas(bp_handle *h);
 static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs);
@@ -218,13 +227,11 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     HK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
     HK(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
     HK(hipEventCreateWithFlags(&h->ev_retired, hipEventDisableTiming));
-    HK(hipEventCreateWithFlags(&h->ev_staging, hipEventDisableTiming));
+    HK(hipEventCreateWithFlags(&h->ev_wretired, hipEventDisableTiming));
     const int L = h->L;
     const size_t Bp = (size_t)((h->B + 63) & ~63);             // bunch rows rounded up to a whole tile
-    const size_t capp = (size_t)h->cap + 64;
-    CK(dev_alloc(h, &h->in, capp * h->ld[0]));
-    if (cfg->dropoutflag == 1 && h->th_vis) CK(dev_alloc(h, &h->in_drop, capp * h->ld[0]));
-    CK(dev_alloc(h, &h->targ, capp * h->ld[L - 1]));
+    // (the stacked chunk buffers in / in_drop / targ are allocated by the first stacked upload, ensure_stacked():
+    // a caller that only ever hands window chunks never pays for them)
     CK(dev_alloc(h, &h->out_dev, Bp * h->ld[L - 1]));
     // narrow output layer (e.g. 2048 -> 257): too few 32x32 tiles to fill 256 CUs, so its k range is
     // split over 4 workgroup rows that write partial-sum slabs; bp_out_reduce finishes the layer
@@ -299,7 +306,7 @@ extern "C" int bp_set_hyper(bp_handle *h, float lrate, float momentum, float wei
     if (dropoutflag != h->cfg.dropoutflag || visible_omit != h->cfg.visible_omit || hid_omit != h->cfg.hid_omit) {
         HIPCHK(hipSetDevice(h->cfg.device));
         const uint32_t th_vis = dropoutflag == 1 ? drop_threshold(visible_omit) : 0u;
-        if (th_vis && !h->in_drop) {
+        if (th_vis && h->in && !h->in_drop) {                   // (no stacked buffers yet: ensure_stacked allocates it with them)
             HIPCHK(hipStreamSynchronize(h->stream));            // (an allocation in the middle of queued bunches: drain first)
             r = dev_alloc(h, &h->in_drop, ((size_t)h->cap + 64) * h->ld[0]);
             if (r != BP_OK) return r;
@@ -507,7 +514,7 @@ static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const
 }
 
 // visible-layer dropout active: bunches read the masked copy of the chunk
-static inline bool use_mask(const bp_handle *h) { return h->in_drop && h->th_vis; }
+static inline bool use_mask(const bp_handle *h) { return !h->windows && h->in_drop && h->th_vis; }
 
 static hipError_t mask_range(bp_handle *h, int first, int n)
 {
@@ -701,16 +708,22 @@ static hipError_t bunch(bp_handle *h, int first, bool fused)
     const int L = h->L, B = h->B;
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
-    const float *x0 = h->in + (size_t)first * h->ld[0];
-    if (h->inj_x0) x0 = h->inj_x0;                      // bp_train_resident_masked: input rows with the injected visible mask
-    else if (use_mask(h)) {
-        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
-                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
-                        (first - h->mask_lo) % B == 0;
-        if (!ok) CKE(mask_range(h, first, B));
-        x0 = h->in_drop + (size_t)first * h->ld[0];
+    const float *x0, *tg;
+    if (h->windows) {                                   // window chunk: stack (and mask) this bunch's rows now
+        CKE(stage_bunch(h, first, B, true));
+        x0 = h->x0s; tg = h->tgs;
+    } else {
+        x0 = h->in + (size_t)first * h->ld[0];
+        tg = h->targ + (size_t)first * h->ld[L - 1];
+        if (h->inj_x0) x0 = h->inj_x0;                  // bp_train_resident_masked: input rows with the injected visible mask
+        else if (use_mask(h)) {
+            const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
+                            (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
+                            (first - h->mask_lo) % B == 0;
+            if (!ok) CKE(mask_range(h, first, B));
+            x0 = h->in_drop + (size_t)first * h->ld[0];
+        }
     }
-    const float *tg = h->targ + (size_t)first * h->ld[L - 1];
     if (h->bf) return bf_bunch(h, x0, tg, fused);
     for (int l = 1; l < L; ++l) {
         CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
@@ -738,6 +751,8 @@ extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, cons
     if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_upload_chunk: n_frames exceeds chunk capacity");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int L = h->L;
+    { const int r = ensure_stacked(h); if (r != BP_OK) return r; }
+    h->windows = false;
     if (n_frames > 0) {
         // into the buffer pair that is not current, on the copy stream: the bunches of the previous chunk (still
         // running on the main stream out of the current pair) overlap this upload
@@ -769,9 +784,9 @@ extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, cons
 }
 
 // ---- on-device frame stacking (host counterpart: Interface.cc:757-797)
-static int raw_reserve(bp_handle *h, int which, size_t bytes)
+static int raw_reserve(bp_handle *h, int set, int which, size_t bytes)
 {
-    bp_handle::Raw &r = h->raw[which];
+    bp_handle::Raw &r = h->wset[set].r[which];
     if (bytes <= r.bytes) return BP_OK;
     if (r.p) {
         HIPCHK(hipStreamSynchronize(h->copy_stream)); HIPCHK(hipStreamSynchronize(h->stream));
@@ -782,6 +797,33 @@ static int raw_reserve(bp_handle *h, int which, size_t bytes)
     if (e != hipSuccess) return fail(BP_ERR_NOMEM, std::string("hipMalloc (window staging): ") + hipGetErrorString(e));
     r.bytes = want;
     return BP_OK;
+}
+
+// The stacked chunk buffers, on the first stacked upload (window chunks never need them).
+static int ensure_stacked(bp_handle *h)
+{
+    const size_t capp = (size_t)h->cap + 64;
+    bool fresh = false;
+    int r;
+    if (!h->in) { if ((r = dev_alloc(h, &h->in, capp * h->ld[0])) != BP_OK) return r; fresh = true; }
+    if (!h->targ) { if ((r = dev_alloc(h, &h->targ, capp * h->ld[h->L - 1])) != BP_OK) return r; fresh = true; }
+    if (h->cfg.dropoutflag == 1 && h->th_vis && !h->in_drop) { if ((r = dev_alloc(h, &h->in_drop, capp * h->ld[0])) != BP_OK) return r; fresh = true; }
+    if (fresh) HIPCHK(hipStreamSynchronize(h->stream));         // (dev_alloc zero-fills on the main stream)
+    return BP_OK;
+}
+
+// Stack rows [first, first+rows) of the resident window chunk into the bunch tile (x0s, and tgs when the chunk carries
+// targets); train: with the visible-layer dropout of this step.
+static hipError_t stage_bunch(bp_handle *h, int first, int rows, bool train)
+{
+    const int L = h->L, ld0 = h->ld[0], ldL = h->ld[L - 1];
+    const int yb_in = (ld0 + 255) / 256, yb_t = h->wv.tg ? (ldL + 255) / 256 : 0;
+    hipLaunchKernelGGL(bp_stage_bunch, dim3((unsigned)((rows + 3) / 4), (unsigned)(yb_in + yb_t)), dim3(256), 0, h->stream,
+                       h->x0s, ld0, h->s[0], h->wv.fea, h->wv.D, h->wv.win, h->wv.nat, h->wv.ws + first,
+                       h->wv.nr ? h->wv.nr + first : (const int *)nullptr, rows, train ? h->th_vis : 0u, h->cfg.rank_frame_offset,
+                       (uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32), h->step, h->wv.tg ? h->tgs : (float *)nullptr, ldL,
+                       h->s[L - 1], h->wv.tg, h->wv.tf ? h->wv.tf + first : (const int *)nullptr, yb_in);
+    return hipGetLastError();
 }
 
 static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ, const char *who)
@@ -806,19 +848,27 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
             return fail(BP_ERR_ARG, std::string(who) + ": nat_row out of range");
     }
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (!h->x0s) {
+        int r;
+        if ((r = dev_alloc(h, &h->x0s, (size_t)h->Bp * h->ld[0])) != BP_OK || (r = dev_alloc(h, &h->tgs, (size_t)h->Bp * h->ld[L - 1])) != BP_OK)
+            return r;
+        HIPCHK(hipStreamSynchronize(h->stream));                // (dev_alloc zero-fills on the main stream)
+    }
     if (n > 0) {
         const size_t fea_b = (size_t)c->n_frames * D * 4, tg_b = with_targ ? (size_t)c->n_frames * sL * 4 : 0;
         const size_t nat_b = nat ? (size_t)c->n_nat * D * 4 : 0, idx_b = (size_t)n * 4;
+        // into the staging set that is not current, on the copy stream: the bunches of the previous chunk (still reading
+        // the current set on the main stream) overlap this upload
+        const int set = 1 - h->wcur;                            // (always alternate: ev_wretired covers exactly the other set)
         int r;
-        if ((r = raw_reserve(h, 0, fea_b)) != BP_OK || (r = raw_reserve(h, 1, tg_b)) != BP_OK ||
-            (r = raw_reserve(h, 2, nat_b)) != BP_OK || (r = raw_reserve(h, 3, 3 * idx_b)) != BP_OK)
+        if ((r = raw_reserve(h, set, 0, fea_b)) != BP_OK || (r = raw_reserve(h, set, 1, tg_b)) != BP_OK ||
+            (r = raw_reserve(h, set, 2, nat_b)) != BP_OK || (r = raw_reserve(h, set, 3, 3 * idx_b)) != BP_OK)
             return r;
-        float *d_fea = (float *)h->raw[0].p, *d_tg = (float *)h->raw[1].p, *d_nat = (float *)h->raw[2].p;
-        int *d_ws = (int *)h->raw[3].p, *d_tf = d_ws + n, *d_nr = d_tf + n;
-        // raw frames + tables -> staging on the copy stream (overlaps the previous chunk's bunches); the expansion
-        // into the chunk buffer is queued on the main stream behind them
+        bp_handle::Raw *rw = h->wset[set].r;
+        float *d_fea = (float *)rw[0].p, *d_tg = (float *)rw[1].p, *d_nat = (float *)rw[2].p;
+        int *d_ws = (int *)rw[3].p, *d_tf = d_ws + n, *d_nr = d_tf + n;
         hipStream_t cs = h->copy_stream;
-        if (h->staging_valid) HIPCHK(hipStreamWaitEvent(cs, h->ev_staging, 0));
+        if (h->wretired_valid) HIPCHK(hipStreamWaitEvent(cs, h->ev_wretired, 0));
         HIPCHK(hipMemcpyAsync(d_fea, c->fea, fea_b, hipMemcpyHostToDevice, cs));
         HIPCHK(hipMemcpyAsync(d_ws, c->win_start, idx_b, hipMemcpyHostToDevice, cs));
         if (nat) {
@@ -832,17 +882,14 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
         HIPCHK(hipEventRecord(h->ev_copy, cs));
         HIPCHK(hipStreamSynchronize(cs));                       // the caller may overwrite its buffers as soon as we return
         HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
-        const int yb = (h->ld[0] + 1023) / 1024 > 0 ? (h->ld[0] + 1023) / 1024 : 1;
-        hipLaunchKernelGGL(bp_expand_windows, dim3((unsigned)n, (unsigned)yb), dim3(256), 0, h->stream, h->in, h->ld[0], h->s[0],
-                           d_fea, D, ctx * D, nat ? d_nat : (const float *)nullptr, d_ws, nat ? d_nr : (const int *)nullptr, n);
-        HIPCHK(hipGetLastError());
-        if (with_targ) {
-            hipLaunchKernelGGL(bp_gather_rows, dim3((unsigned)n, 1), dim3(256), 0, h->stream, h->targ, h->ld[L - 1], sL, d_tg, d_tf, n);
-            HIPCHK(hipGetLastError());
-        }
-        HIPCHK(hipEventRecord(h->ev_staging, h->stream));
-        h->staging_valid = true;
+        HIPCHK(hipEventRecord(h->ev_wretired, h->stream));      // everything queued so far read the other set
+        h->wretired_valid = true;
+        h->wcur = set;
+        h->wv.fea = d_fea; h->wv.tg = with_targ ? d_tg : nullptr; h->wv.nat = nat ? d_nat : nullptr;
+        h->wv.ws = d_ws; h->wv.tf = with_targ ? d_tf : nullptr; h->wv.nr = nat ? d_nr : nullptr;
+        h->wv.D = D; h->wv.win = ctx * D;
     }
+    h->windows = true;
     h->chunk_frames = n;
     h->mask_lo = h->mask_hi = -1;
     return BP_OK;
@@ -859,6 +906,8 @@ extern "C" int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed
     if (n_frames < 0 || n_frames > h->cap) return fail(BP_ERR_ARG, "bp_fill_chunk_synthetic: n_frames exceeds capacity");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int L = h->L;
+    { const int r = ensure_stacked(h); if (r != BP_OK) return r; }
+    h->windows = false;
     if (n_frames > 0) {
         size_t n4 = (size_t)n_frames * (h->ld[0] / 4);
         hipLaunchKernelGGL(bp_fill_normal, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, h->stream, h->in, h->ld[0],
@@ -882,6 +931,8 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     if (h->Bg != h->B && !h->dp)
         return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle: bp_dp_attach it (in-library exchange) or drive "
                                   "bp_grads_resident + bp_apply_update yourself");
+    if (h->windows && n_frames >= h->B && !h->wv.tg)
+        return fail(BP_ERR_STATE, "bp_train_resident: the resident window chunk was uploaded without targets (forward / CV upload)");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int nb = n_frames / h->B;          // partial last bunch ignored (BP_GPU.cu:315-318)
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -936,6 +987,7 @@ extern "C" int bp_train_resident_masked(bp_handle *h, int first_frame, int n_fra
 {
     if (!h || !masks) return fail(BP_ERR_ARG, "bp_train_resident_masked: null argument");
     if (h->bf || h->dp || h->Bg != h->B) return fail(BP_ERR_STATE, "bp_train_resident_masked: fp32 single-device handles only");
+    if (h->windows) return fail(BP_ERR_STATE, "bp_train_resident_masked: stacked chunks only (bp_upload_chunk)");
     if (first_frame < 0 || n_frames < 0 || first_frame + n_frames > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_train_resident_masked: frame range outside the resident chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1484,14 +1536,20 @@ static hipError_t dp_bunch(bp_handle *h, int first)
     const int L = h->L, B = h->B;
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
-    const float *x0 = h->in + (size_t)first * h->ld[0];
-    if (use_mask(h)) {
-        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
-                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step && (first - h->mask_lo) % B == 0;
-        if (!ok) CKE(mask_range(h, first, B));
-        x0 = h->in_drop + (size_t)first * h->ld[0];
+    const float *x0, *tg;
+    if (h->windows) {                                   // window chunk: stack (and mask) this bunch's rows now
+        CKE(stage_bunch(h, first, B, true));
+        x0 = h->x0s; tg = h->tgs;
+    } else {
+        x0 = h->in + (size_t)first * h->ld[0];
+        tg = h->targ + (size_t)first * h->ld[L - 1];
+        if (use_mask(h)) {
+            const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
+                            (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step && (first - h->mask_lo) % B == 0;
+            if (!ok) CKE(mask_range(h, first, B));
+            x0 = h->in_drop + (size_t)first * h->ld[0];
+        }
     }
-    const float *tg = h->targ + (size_t)first * h->ld[L - 1];
     const unsigned prev_epoch = d->epoch;
     d->epoch++;
     if (h->bf) {
@@ -1626,12 +1684,14 @@ static int forward_bunch(bp_handle *h, int first, int fb)
     const int L = h->L;
     const float vis_keep = 1.0f - h->cfg.visible_omit, hid_keep = 1.0f - h->cfg.hid_omit;   // BP_GPU.cu:703-704
     float *out = h->out_chunk + (size_t)first * h->ld[L - 1];
-    if (h->bf) HIPCHK(bf_input(h, h->in + (size_t)first * h->ld[0], fb));
+    const float *x0 = h->windows ? h->x0s : h->in + (size_t)first * h->ld[0];
+    if (h->windows) HIPCHK(stage_bunch(h, first, fb, false));
+    if (h->bf) HIPCHK(bf_input(h, x0, fb));
     for (int l = 1; l < L; ++l) {
         float alpha = 1.0f;
         if (h->cfg.dropoutflag == 1) alpha = (l == 1) ? vis_keep : hid_keep;
         if (h->bf) { HIPCHK(bf_fwd(h, l, fb, nullptr, out, false, alpha)); continue; }
-        const float *yp = (l == 1) ? h->in + (size_t)first * h->ld[0] : h->y[l - 1];
+        const float *yp = (l == 1) ? x0 : h->y[l - 1];
         HIPCHK(launch_fwd(h, h->stream, l, fb, yp, nullptr, out, false, alpha));
     }
     return BP_OK;
@@ -1847,7 +1907,7 @@ extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
     if (h->L < 4 && (which == 0 || which == 1 || which == 2))
         return fail(BP_ERR_ARG, "bp_time_kernel: needs a hidden->hidden layer (numlayers >= 4)");
     if (h->bf) return fail(BP_ERR_STATE, "bp_time_kernel: fp32 kernels only");
-    if (h->chunk_frames < h->B) return fail(BP_ERR_STATE, "bp_time_kernel: no resident chunk");
+    if (h->chunk_frames < h->B || h->windows) return fail(BP_ERR_STATE, "bp_time_kernel: no resident stacked chunk");
     HIPCHK(hipSetDevice(h->cfg.device));
     const int L = h->L, B = h->B;
     hipEvent_t a, b;

@@ -901,34 +901,41 @@ __global__ __launch_bounds__(256, K::MIN_WG) void bp_gemm_multi(const MultiArgs 
 }
 
 // ------------------------------------------------------------------ small kernels
-// On-device frame stacking (include/bp_c_api.h, bp_window_chunk; Interface.cc:757-790 does this on the
-// host): row i of the chunk = `win` consecutive floats of the raw frame matrix starting at frame
-// win_start[i] (the context window is contiguous in memory), then the sentence's noise-aware block,
-// then zero padding up to ld.  blockIdx.x = sample, blockIdx.y x threads sweep the columns (coalesced 4-byte
-// accesses: raw rows of 257 floats are not 16-byte aligned).
-__global__ void bp_expand_windows(float *out, int ld, int width, const float *fea, int fea_dim, int win,
-                                  const float *nat, const int *win_start, const int *nat_row, int n_samples)
+// On-device frame stacking, one bunch at a time (include/bp_c_api.h, bp_window_chunk; the host does it per chunk,
+// Interface.cc:757-797).  Rows 0..rows-1 of the bunch (the caller passes the tables already offset to its first sample)
+// become the input tile x [rows][ld]: `win` consecutive floats of the raw frame matrix starting at frame win_start[i]
+// (a context window is contiguous in memory), then the sentence's noise-aware block, then zero padding up to ld -- with
+// the visible-layer dropout of BP_GPU.cu:536-539 drawn on the way (thresh != 0; the Philox words of bp_mask_input:
+// key (global frame >> 2, unit), layer 0) -- and the bunch's targets t [rows][ldt] = targ_frames[targ_frame[i]]
+// (Interface.cc:792-797; t may be null).  The stacked chunk (n_samples x 2827 floats) and its masked copy are never
+// materialised: what stays resident are the raw frames (11x fewer bytes) and this one L2-sized tile per bunch.
+// One thread = one column x 4 consecutive rows (= one Philox block; coalesced 4-byte accesses: raw rows of 257 floats
+// are not 16-byte aligned); blockIdx.y < yb_in sweeps the input columns, the rest the target columns.
+__global__ void bp_stage_bunch(float *x, int ld, int width, const float *fea, int fea_dim, int win, const float *nat,
+                               const int *win_start, const int *nat_row, int rows, uint32_t thresh, int frame_off,
+                               uint32_t seed_lo, uint32_t seed_hi, uint32_t step, float *t, int ldt, int twidth,
+                               const float *targ_frames, const int *targ_frame, int yb_in)
 {
-    const int i = blockIdx.x;
-    if (i >= n_samples) return;
-    const float *src = fea + (size_t)win_start[i] * fea_dim;
-    const float *nsrc = nat ? nat + (size_t)nat_row[i] * fea_dim : nullptr;
-    float *dst = out + (size_t)i * ld;
-    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < ld; c += gridDim.y * blockDim.x) {
-        float v = 0.0f;
-        if (c < win) v = src[c];
-        else if (c < width) v = nsrc[c - win];
-        dst[c] = v;
+    const int r0 = blockIdx.x * 4;
+    if ((int)blockIdx.y >= yb_in) {
+        const int c = ((int)blockIdx.y - yb_in) * blockDim.x + threadIdx.x;
+        if (c >= ldt) return;
+        for (int j = 0; j < 4 && r0 + j < rows; ++j)
+            t[(size_t)(r0 + j) * ldt + c] = c < twidth ? targ_frames[(size_t)targ_frame[r0 + j] * twidth + c] : 0.0f;
+        return;
     }
-}
-// targ[i] = targ_frames[targ_frame[i]] (Interface.cc:792-797), zero padded to ld
-__global__ void bp_gather_rows(float *out, int ld, int width, const float *rows, const int *row_of, int n_samples)
-{
-    const int i = blockIdx.x;
-    if (i >= n_samples) return;
-    const float *src = rows + (size_t)row_of[i] * width;
-    float *dst = out + (size_t)i * ld;
-    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < ld; c += gridDim.y * blockDim.x) dst[c] = c < width ? src[c] : 0.0f;
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= ld) return;
+    uint32_t w[4] = {~0u, ~0u, ~0u, ~0u};
+    if (thresh && c < width) drop_words4(w, r0, c, frame_off, (uint32_t)width, 0u, step, seed_lo, seed_hi);
+    for (int j = 0; j < 4 && r0 + j < rows; ++j) {
+        const int r = r0 + j;
+        float v = 0.0f;
+        if (c < win) v = fea[(size_t)win_start[r] * fea_dim + c];
+        else if (c < width) v = nat[(size_t)nat_row[r] * fea_dim + (c - win)];
+        if (w[j] < thresh) v = 0.0f;
+        x[(size_t)r * ld + c] = v;
+    }
 }
 
 // Visible-layer dropout of the resident chunk (BP_GPU.cu:536-539 masks the device copy of the

@@ -370,18 +370,21 @@ def _window_case(rs, nat, n_frames=300, D=21, ctx=5, od=17, n=200):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nat", [False, True])
-def test_window_chunk_equals_stacked_chunk(pkg, nat):
+@pytest.mark.parametrize("nat,dtype", [(False, 0), (True, 0), (True, 1)])
+def test_window_chunk_equals_stacked_chunk(pkg, nat, dtype):
+    """a chunk handed over as raw frames + index tables (every bunch stacks and masks its own rows on the
+    device, bp_stage_bunch) trains and cross-validates bit-identically to the same chunk handed over stacked by the host
+    (Interface.cc:757-797) -- visible + hidden dropout on, noise-aware block, partial last bunch in CV, fp32 and bf16."""
     rs = np.random.default_rng(31)
     D, ctx, od, B = 21, 5, 17, 32
     fea, tg, ws, tf, natm, nr, rows, trows = _window_case(rs, nat, D=D, ctx=ctx, od=od)
     ls = [rows.shape[1], 70, od]
     W = [None] + [(rs.normal(size=(ls[l - 1], ls[l])) * 0.1).astype(np.float32) for l in (1, 2)]
     b = [None] + [(rs.normal(size=ls[l]) * 0.1).astype(np.float32) for l in (1, 2)]
-    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=5)
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=5, compute_dtype=dtype)
     g1 = pkg.BP_GPU(1, 3, ls, B, 0.5, 0.5, 1e-4, W, b, **kw)
     g2 = pkg.BP_GPU(1, 3, ls, B, 0.5, 0.5, 1e-4, W, b, **kw)
-    for _ in range(2):                                           # two chunks: staging buffers are reused
+    for _ in range(2):                                           # two chunks: the staging sets alternate
         g1.train(rows.shape[0], rows, trows)
         g2.train_windows(fea, tg, ctx, ws, tf, natm, nr)
     e1 = g1.CrossValid(rows.shape[0], rows, trows)
@@ -393,6 +396,37 @@ def test_window_chunk_equals_stacked_chunk(pkg, nat):
     for l in (1, 2):
         assert np.array_equal(g1.W_[l], g2.W_[l]) and np.array_equal(g1.b_[l], g2.b_[l])
     assert not np.array_equal(g1.W_[1], W[1])
+    g1.close(); g2.close()
+
+
+@pytest.mark.gpu
+def test_window_and_stacked_chunks_interleave_at_benchmark_geometry(pkg):
+    """The geometry of BASELINE.json's C2 input (11 frames x 257 bins = 2827, rows of 257 floats are not 16-byte aligned,
+    256-frame bunches) on one handle that is fed window chunks and stacked chunks in turn, several uploads queued back to
+    back (the two staging sets and the two stacked buffer pairs alternate while earlier bunches are still running),
+    against a second handle that only ever sees stacked rows: same weights, bit for bit."""
+    rs = np.random.default_rng(33)
+    D, ctx, od, B = 257, 11, 257, 256
+    ls = [D * ctx, 192, od]
+    W = [None] + [(rs.normal(size=(ls[l - 1], ls[l])) * 0.02).astype(np.float32) for l in (1, 2)]
+    b = [None] + [(rs.normal(size=ls[l]) * 0.02).astype(np.float32) for l in (1, 2)]
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=9)
+    g1 = pkg.BP_GPU(1, 3, ls, B, 0.05, 0.5, 0.0, W, b, max_chunk_frames=1024, **kw)
+    g2 = pkg.BP_GPU(1, 3, ls, B, 0.05, 0.5, 0.0, W, b, max_chunk_frames=1024, **kw)
+    for i in range(5):
+        n = (1024, 700, 512, 1000, 256)[i]
+        fea, tg, ws, tf, _, _, rows, trows = _window_case(rs, False, n_frames=900 + 37 * i, D=D, ctx=ctx, od=od, n=n)
+        g1.train(n, rows, trows)
+        if i % 3 == 2:
+            g2.train(n, rows, trows)                             # a stacked chunk between window chunks
+        else:
+            g2.train_windows(fea, tg, ctx, ws, tf)
+    for g in (g1, g2):
+        g.W_, g.b_ = [None] + [np.zeros_like(W[l]) for l in (1, 2)], [None] + [np.zeros_like(b[l]) for l in (1, 2)]
+        g.returnWeights(g.W_, g.b_)
+    for l in (1, 2):
+        assert np.array_equal(g1.W_[l], g2.W_[l]) and np.array_equal(g1.b_[l], g2.b_[l])
+    g1.close(); g2.close()
 
 
 @pytest.mark.gpu
