@@ -911,31 +911,39 @@ __global__ __launch_bounds__(256, K::MIN_WG) void bp_gemm_multi(const MultiArgs 
 // materialised: what stays resident are the raw frames (11x fewer bytes) and this one L2-sized tile per bunch.
 // One thread = one column x 4 consecutive rows (= one Philox block; coalesced 4-byte accesses: raw rows of 257 floats
 // are not 16-byte aligned); blockIdx.y < yb_in sweeps the input columns, the rest the target columns.
-__global__ void bp_stage_bunch(float *x, int ld, int width, const float *fea, int fea_dim, int win, const float *nat,
-                               const int *win_start, const int *nat_row, int rows, uint32_t thresh, int frame_off,
-                               uint32_t seed_lo, uint32_t seed_hi, uint32_t step, float *t, int ldt, int twidth,
-                               const float *targ_frames, const int *targ_frame, int yb_in)
+__global__ void bp_stage_bunch(float *__restrict__ x, int ld, int width, const float *__restrict__ fea, int fea_dim, int win,
+                               const float *__restrict__ nat, const int *__restrict__ win_start, const int *__restrict__ nat_row,
+                               int rows, uint32_t thresh, int frame_off, uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
+                               float *__restrict__ t, int ldt, int twidth, const float *__restrict__ targ_frames,
+                               const int *__restrict__ targ_frame, int yb_in)
 {
     const int r0 = blockIdx.x * 4;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if ((int)blockIdx.y >= yb_in) {
         const int c = ((int)blockIdx.y - yb_in) * blockDim.x + threadIdx.x;
         if (c >= ldt) return;
-        for (int j = 0; j < 4 && r0 + j < rows; ++j)
-            t[(size_t)(r0 + j) * ldt + c] = c < twidth ? targ_frames[(size_t)targ_frame[r0 + j] * twidth + c] : 0.0f;
+        if (c < twidth) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = targ_frames[(size_t)targ_frame[r0 + j] * twidth + c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j < rows) t[(size_t)(r0 + j) * ldt + c] = v[j];
         return;
     }
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     if (c >= ld) return;
+    // all four rows' loads first (independent), the Philox block meanwhile, then the four stores
+    if (c < win) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = fea[(size_t)win_start[r0 + j] * fea_dim + c];
+    } else if (c < width) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = nat[(size_t)nat_row[r0 + j] * fea_dim + (c - win)];
+    }
     uint32_t w[4] = {~0u, ~0u, ~0u, ~0u};
     if (thresh && c < width) drop_words4(w, r0, c, frame_off, (uint32_t)width, 0u, step, seed_lo, seed_hi);
-    for (int j = 0; j < 4 && r0 + j < rows; ++j) {
-        const int r = r0 + j;
-        float v = 0.0f;
-        if (c < win) v = fea[(size_t)win_start[r] * fea_dim + c];
-        else if (c < width) v = nat[(size_t)nat_row[r] * fea_dim + (c - win)];
-        if (w[j] < thresh) v = 0.0f;
-        x[(size_t)r * ld + c] = v;
-    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (r0 + j < rows) x[(size_t)(r0 + j) * ld + c] = w[j] < thresh ? 0.0f : v[j];
 }
 
 // Visible-layer dropout of the resident chunk (BP_GPU.cu:536-539 masks the device copy of the

@@ -139,8 +139,10 @@ int bp_train_resident_masked(bp_handle *h, int first_frame, int n_frames, const 
  * On-device frame stacking.  The reference's reader materialises every
  * sample on the host as `context` consecutive normalised frames [+ the noise-aware block]
  * (Interface.cc:757-790) and uploads context x the raw volume.  Here the caller hands over the
- * RAW normalised frames of the chunk once plus three index tables; the library expands them
- * into the resident chunk on the device.  Row i of the expanded chunk is
+ * RAW normalised frames of the chunk once plus three index tables; they STAY raw in device
+ * memory and every bunch (training, CV, forward) stacks -- and, in training, dropout-masks -- its
+ * own rows right before its layer-1 kernels: the stacked chunk is never materialised.  Row i of
+ * the chunk, as the network sees it, is
  *     in[i]   = fea[win_start[i] .. win_start[i]+context)   (context*fea_dim contiguous floats)
  *               ++ nat[nat_row[i]]                          (fea_dim floats, only when nat != NULL)
  *     targ[i] = targ_frames[targ_frame[i]]                  (layersizes[L-1] floats)
@@ -148,7 +150,7 @@ int bp_train_resident_masked(bp_handle *h, int first_frame, int n_frames, const 
  * context*fea_dim (+ fea_dim with a NAT block).  The caller may overwrite everything as soon
  * as the call returns. */
 typedef struct bp_window_chunk {
-    int n_samples;             /* rows of the expanded chunk (<= chunk capacity) */
+    int n_samples;             /* rows (samples) of the chunk (<= chunk capacity) */
     int n_frames;              /* raw frames in fea / targ_frames */
     int fea_dim, context;
     int n_nat;                 /* rows of nat (0 when nat == NULL) */
@@ -160,7 +162,7 @@ typedef struct bp_window_chunk {
     const int *nat_row;        /* [n_samples] or NULL */
 } bp_window_chunk;
 int bp_upload_chunk_windows(bp_handle *h, const bp_window_chunk *c);             /* then bp_train_resident etc. */
-int bp_train_chunk_windows(bp_handle *h, const bp_window_chunk *c);              /* = BP_GPU::train on the expanded chunk */
+int bp_train_chunk_windows(bp_handle *h, const bp_window_chunk *c);              /* = BP_GPU::train on the stacked chunk */
 int bp_cv_chunk_windows(bp_handle *h, const bp_window_chunk *c, float *sq_err_sum); /* = BP_GPU::CrossValid */
 int bp_forward_windows(bp_handle *h, const bp_window_chunk *c, float *out);         /* = bp_forward: out[n_samples][sL] (enhancement) */
 
