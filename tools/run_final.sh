@@ -6,3 +6,4 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $O/smoke
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line.json 2> $O/bench.err; tail -c 400 $O/bench_line.json; echo
 python bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench2_line.json 2> $O/bench2.err; tail -c 300 $O/bench2_line.json; echo
 timeout 600 python tools/bench_bptrain.py 4000 420 > $O/bptrain.json 2>$O/bptrain.err; cat $O/bptrain.json
+python tools/bench_windows.py > $O/bench_windows.json 2> $O/bench_windows.err; cat $O/bench_windows.json
