@@ -258,6 +258,7 @@ def parse_args():
     ap.add_argument("--prewarm-s", type=float, default=1.5, help="seconds of real untimed training steps before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the C5 line and the measured peaks")
+    ap.add_argument("--sustained-s", type=float, default=4.0, help="seconds of the additional sustained-rate measurement (0 = skip)")
     ap.add_argument("--chunk", type=int, default=CHUNK)
     ap.add_argument("--exchange", choices=["native", "rccl"], default="native",
                     help="transport of the data-parallel exchange (N > 1): the library's peer kernels, or RCCL reduce-scatter/all-gather")
@@ -389,11 +390,23 @@ def main():
 
     frames = args.steps * BUNCH * world
     value = frames / dt
+    # ---- sustained rate (an extra field, not `value`): the same steps for --sustained-s seconds, so that clocks, power and
+    # temperature are at their steady state -- and so that whoever samples the GPU's busy counter during this run sees it
+    sustained = None
+    if args.sustained_s > 0 and not args.no_extras:
+        n_sus = int(max_over_ranks(float(max(1, int(args.sustained_s / (dt / args.steps))))))      # same count on every rank
+        barrier()
+        t1 = time.perf_counter()
+        pos = run(n_sus, pos)
+        barrier()
+        dt_s = max_over_ranks(time.perf_counter() - t1)
+        sustained = {"seconds": dt_s, "steps": n_sus, "value": n_sus * BUNCH * world / dt_s, "unit": "frames/s",
+                     "ms_per_step": 1e3 * dt_s / n_sus}
     res = {
         "metric": "training frames/sec (257x11 input, 3x2048 DNN)", "value": value, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "prewarm_s": prewarm_s, "prewarm_steps": prewarm_steps,
+        "prewarm_s": prewarm_s, "prewarm_steps": prewarm_steps, "sustained": sustained,
         "config": {"workload": "C2: 2827->2048->2048->2048->257 ReLU+dropout(0.1/0.2), fp32, %d frames/GPU/step "
                                "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
                                % (BUNCH, BUNCH * world, chunk),
