@@ -81,6 +81,21 @@ int main(int argc, char **argv)
             }
             printf("  k-tile durations: t0 %.2f t1 %.2f t2 %.2f t3 %.2f, t4..7 avg %.2f us\n", d[0], d[1], d[2], d[3], d[4]);
         }
+        if (!wgrad) {     // drift inside the groups of 8 m-tile workgroups that stream the same weight panel through one XCD's L2
+            double sp_entry = 0, sp_loop = 0, sp_max = 0;
+            for (int xcd = 0; xcd < 8; ++xcd)
+                for (int tn = 0; tn < 4; ++tn) {
+                    double lo0 = 1e30, hi0 = 0, lo2 = 1e30, hi2 = 0;
+                    for (int tm = 0; tm < 8; ++tm) {
+                        const int b = xcd + 8 * (tn * 8 + tm);
+                        const double t0b = (h[((size_t)l * NWG + b) * 8 + 0] - t0) * 0.01, t2b = (h[((size_t)l * NWG + b) * 8 + 2] - t0) * 0.01;
+                        lo0 = std::min(lo0, t0b); hi0 = std::max(hi0, t0b); lo2 = std::min(lo2, t2b); hi2 = std::max(hi2, t2b);
+                    }
+                    sp_entry += (hi0 - lo0) / 32; sp_loop += (hi2 - lo2) / 32; sp_max = std::max(sp_max, hi2 - lo2);
+                }
+            printf("  8 workgroups of one weight panel: spread of entry %.2f us, of k-loop end %.2f us on average (max %.2f); one k-tile = %.2f us\n",
+                   sp_entry, sp_loop, sp_max, dur[1] / ((K + 63) / 64));
+        }
         if (!wg64) {
             double mhz = 0; int cnt = 0;
             for (int b = 0; b < NWG; ++b) {
