@@ -59,12 +59,18 @@ struct WgradDma {
 #pragma unroll
         for (int s = 0; s < RD; ++s) { av[s] = ap[2 * s * BM]; bv[s] = bp[2 * s * BN]; }
         __builtin_amdgcn_sched_barrier(0);
+#if defined(BP_WG_SETPRIO) && BP_WG_SETPRIO     // development A/B: the 4 workgroups of a CU are independent and out of phase (guide T5)
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
             acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[s & 1], 0, 0, 0);
             if (s + RD < NK) { av[s + RD] = ap[2 * (s + RD) * BM]; bv[s + RD] = bp[2 * (s + RD) * BN]; }
             __builtin_amdgcn_sched_barrier(0);
         }
+#if defined(BP_WG_SETPRIO) && BP_WG_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     }
     template <int T>
     static __device__ __forceinline__ void iter(const GemmArgs &g, const EpiArgs &e, int m0, int n0, float *smem, int wave, int lane, int tid,

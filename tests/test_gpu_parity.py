@@ -191,27 +191,7 @@ C2 = [257 * 11, 2048, 2048, 2048, 257]
 C3 = [257 * 12, 2048, 2048, 2048, 257]          # 11 frames + the appended noise-estimate block (NAT)
 
 
-def relu_flips(y_gpu, y_ref, y_prev, Wl, bl):
-    """Units of one hidden layer whose ReLU state differs between the device and the reference although both saw the
-    same inputs and (up to rounding) the same pre-activation.  Returns [(frame, unit, |x| of the side that is on,
-    rounding scale)], rounding scale = 2^-24 * (sum_k |y_prev[f,k] * W[k,n]| + |b[n]|): the size of one fp32 rounding
-    error of that dot product.  (Units dropped by dropout are 0 on both sides and never differ.)"""
-    fl = []
-    for f, n in zip(*np.nonzero((y_gpu > 0) != (y_ref > 0))):
-        mag = float(max(abs(y_gpu[f, n]), abs(y_ref[f, n])))
-        scale = float((np.abs(y_prev[f].astype(np.float64) * Wl[:, n].astype(np.float64)).sum() + abs(float(bl[n]))) * 2.0 ** -24)
-        fl.append((int(f), int(n), mag, scale))
-    return fl
-
-
-def backprop_rows(ls, W, ys, out, t, rows, n_scale):
-    """fp64 dEdX_l rows of the given frames from that side's OWN activations (dEdX_L = (2/n)(out - t), BP_GPU.cu:630;
-    dEdX_{l-1} = (y_{l-1} > 0) * dEdX_l . W_l^T, :611-637): what those frames contribute to every layer's gradient."""
-    L = len(ls)
-    dx = {L - 1: (2.0 / n_scale) * (out[rows].astype(np.float64) - t[rows].astype(np.float64))}
-    for l in range(L - 1, 1, -1):
-        dx[l - 1] = (ys[l - 1][rows] > 0) * (dx[l] @ W[l].astype(np.float64).T)
-    return dx
+from flip_accounting import backprop_rows, relu_flips  # noqa: E402  (shared with test_gpu_autograd.py)
 
 
 @pytest.mark.parametrize("ls,drop", [(C2, True), (C3, False)])

@@ -172,3 +172,48 @@ def test_oracle_trajectory_matches_torch_fp64_at_1024_wide(oracle_mod, act, rule
     assert relerr(o.forward(x), y.numpy()) < 1e-5
     sq = float(((y - torch.tensor(t, dtype=torch.float64)) ** 2).sum())
     assert abs(o.crossvalid(x, t) - sq) < 1e-4 * sq
+
+
+def test_test_side_philox_equals_oracle_mask_stream(oracle_mod):
+    """tests/philox_np.py (the numpy Philox the oracle-free GPU backward test draws its masks with) produces the oracle's
+    masks: seeds with and without high bits, several steps, layers, and frame offsets that are not multiples of 4."""
+    from philox_np import drop_mask
+    ls, B = [37, 50, 21, 9], 23
+    W, b = N.glorot_net(ls, seed=1)
+    for seed in (31, (5 << 32) | 7):
+        o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=seed)
+        for step in (0, 3):
+            for layer in (0, 1, 2):
+                for off in (0, 5, 8):
+                    assert np.array_equal(o.fill_mask(step, layer, B, off), drop_mask(seed, step, layer, B, ls[layer], 0.1 if layer == 0 else 0.2, off))
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_torch_reference_of_the_gpu_backward_test_equals_oracle_gradient(oracle_mod, act):
+    """tests/torch_ref.py (torch float64 autograd with non-inverted dropout on the layer outputs, optional removal of
+    frames from the loss) against the oracle's gradient with the same masks: the reference the GPU backward test uses is
+    itself pinned on the CPU, and the oracle once more by something that shares no code with it."""
+    pytest.importorskip("torch")
+    from torch_ref import torch_grads
+    ls, B = [70, 96, 64, 33], 48
+    W, b = N.glorot_net(ls, seed=4, beta=1.5)
+    rng = np.random.default_rng(8)
+    b = [None] + [rng.normal(size=ls[l]).astype(np.float32) * 0.2 for l in range(1, len(ls))]
+    x = rng.normal(size=(B, ls[0])).astype(np.float32)
+    t = rng.normal(size=(B, ls[-1])).astype(np.float32)
+    o = oracle_mod.Oracle(ls, B, weights=W, bias=b, activation=act, acc_double=True, dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=9)
+    masks = [o.fill_mask(0, l, B) for l in range(len(ls) - 1)]
+    gw, gb, ys, out = o.grads(x, t, masks=masks)
+    tw, tb, tys, tout = torch_grads(ls, W, b, x, t, masks, act=act)
+    assert relerr(out, tout) < 1e-6
+    for l in range(1, len(ls)):
+        assert relerr(gw[l], tw[l]) < 1e-5 and relerr(gb[l], tb[l]) < 1e-5, l
+    for l in range(len(ls) - 1):
+        assert relerr(ys[l], tys[l]) < 1e-6
+    # frames removed from the loss == the full gradient minus those frames' contributions
+    keep = np.ones(B, bool); keep[[3, 17]] = False
+    kw, kb, _, _ = torch_grads(ls, W, b, x, t, masks, keep_rows=keep, act=act)
+    xs, ts, ms = x[[3, 17]], t[[3, 17]], [m[[3, 17]] for m in masks]
+    rw, rb, _, _ = torch_grads(ls, W, b, xs, ts, ms, act=act)
+    for l in range(1, len(ls)):
+        assert relerr(kw[l], tw[l] - rw[l] * (2.0 / B)) < 1e-9, l
