@@ -333,15 +333,31 @@ def main():
     rank_table = None
     exchange_used, exchange_note = args.exchange, None
     if dp:
+        # The native exchange checks its memory-model assumptions on the group's real devices at attach and refuses to run when
+        # they do not hold.  Rather than produce no number, the group then falls back to the RCCL transport of the same step and
+        # says so in the line -- but only TOGETHER: every rank's verdict is all-gathered over a host-only rendezvous first
+        # (a failure seen by one rank alone, e.g. a timeout, must not send the ranks to different keys).
+        err = None
         try:
             g.dp_attach(world, rank, key, transport=1 if args.exchange == "rccl" else 0)
         except dnnse_amd.BPError as e:
-            # The native exchange checks its memory-model assumptions on the group's real devices at attach and refuses to
-            # run when they do not hold (every rank sees the same verdict: it is all-gathered).  Rather than produce no
-            # number, fall back to the RCCL transport of the same step and say so in the line.
+            err = str(e)[:200]
+        if world > 1:
+            rv = dnnse_amd.Rendezvous(key + "-verdict", world, rank, timeout_s=120.0)
+            n_failed = sum(rv.allgather_f64(1.0 if err else 0.0))
+            rv.close()
+        else:
+            n_failed = 1 if err else 0
+        if n_failed:
             if args.exchange != "native" or world == 1:
-                raise
-            exchange_used, exchange_note = "rccl", "native attach failed (%s); fell back to the RCCL transport" % str(e)[:200]
+                raise dnnse_amd.BPError(err or "a peer rank failed to attach")
+            if err is None:
+                try:
+                    g.dp_detach()                               # attached here, but a peer was not: leave that group
+                except dnnse_amd.BPError:
+                    pass                                        # (its closing barrier cannot complete without that peer)
+            exchange_used = "rccl"
+            exchange_note = "native attach failed on %d of %d ranks (%s); the group fell back to the RCCL transport" % (int(n_failed), world, err or "on a peer")
             g.dp_attach(world, rank, key + "-rccl", transport=1)
         # what each rank attached to, as the library saw it: a reader can check N ranks on N devices
         rank_table = []

@@ -929,8 +929,8 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     if (first_frame < 0 || n_frames < 0 || first_frame + n_frames > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_train_resident: frame range outside the resident chunk");
     if (h->Bg != h->B && !h->dp)
-        return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle: bp_dp_attach it (in-library exchange) or drive "
-                                  "bp_grads_resident + bp_apply_update yourself");
+        return fail(BP_ERR_STATE, "bp_train_resident: data-parallel handle (global_bunchsize != bunchsize): attach it to its group first "
+                                  "(bp_dp_attach: the exchange and the sharded update run inside the library)");
     if (h->windows && n_frames >= h->B && !h->wv.tg)
         return fail(BP_ERR_STATE, "bp_train_resident: the resident window chunk was uploaded without targets (forward / CV upload)");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -1041,6 +1041,10 @@ extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
     if (first_frame < 0 || first_frame + h->B > h->chunk_frames)
         return fail(BP_ERR_ARG, "bp_grads_resident: bunch outside the resident chunk");
     if (h->dp) return fail(BP_ERR_STATE, "bp_grads_resident: not on an attached handle (the exchange owns the gradient buffer)");
+    //  a window chunk uploaded for forward / CV carries no targets: bunch() would stage only the input rows and
+    // back-propagate against whatever an earlier bunch left in the staged target tile
+    if (h->windows && !h->wv.tg)
+        return fail(BP_ERR_STATE, "bp_grads_resident: the resident window chunk was uploaded without targets (forward / CV upload)");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
     HIPCHK(bunch(h, first_frame, false));

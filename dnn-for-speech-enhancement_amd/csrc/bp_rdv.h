@@ -97,6 +97,26 @@ static int rdv_open(const char *key, int world, int rank, double timeout_s, bp_r
     r->timeout_s = timeout_s > 0.5 ? timeout_s : 0.5; r->name_live = false;
     const double t0 = rdv_now();
     if (rank == 0) {
+        // Whatever carries the name is either the stale block of a crashed job (replace it) or the block of a LIVE job that is
+        // still joining under the same key (unlinking that one would send its late ranks into OUR block): look first.
+        {
+            const int fd0 = shm_open(r->name.c_str(), O_RDWR, 0600);
+            if (fd0 >= 0) {
+                struct stat st0;
+                bool live = false;
+                if (fstat(fd0, &st0) == 0 && (size_t)st0.st_size >= sizeof(RdvShm)) {
+                    void *p0 = mmap(nullptr, sizeof(RdvShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd0, 0);
+                    if (p0 != MAP_FAILED) {
+                        const RdvShm *s0 = (const RdvShm *)p0;
+                        live = s0->magic.load(std::memory_order_acquire) == BP_RDV_MAGIC && s0->creator_pid != (int)getpid() &&
+                               rdv_pid_alive(s0->creator_pid) && !s0->abort_flag.load();
+                        munmap(p0, sizeof(RdvShm));
+                    }
+                }
+                close(fd0);
+                if (live) { g_rdv_err = "rendezvous: a live job is already joining under the key of " + r->name + " (keys must be unique per job)"; delete r; return -3; }
+            }
+        }
         shm_unlink(r->name.c_str());                              // a stale block of a crashed job with this key, if any
         const int fd = shm_open(r->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0 || ftruncate(fd, sizeof(RdvShm)) != 0) {
@@ -132,8 +152,19 @@ static int rdv_open(const char *key, int world, int rank, double timeout_s, bp_r
             }
             // not published yet, or left behind by a dead job: look again until rank 0's block is there
             if (!ready || !rdv_pid_alive(s->creator_pid) || s->abort_flag.load()) { munmap(p, sizeof(RdvShm)); usleep(200); continue; }
+            // claim the rank's slot: a second process that arrives with the same rank is an error, not a silent overwrite
+            int expected = 0;
+            if (!__atomic_compare_exchange_n(&s->pid[rank], &expected, (int)getpid(), false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE) && expected != (int)getpid()) {
+                if (!rdv_pid_alive(expected)) { munmap(p, sizeof(RdvShm)); usleep(200); continue; }       // (a stale block whose creator pid was reused)
+                munmap(p, sizeof(RdvShm));
+                g_rdv_err = "rendezvous: rank " + std::to_string(rank) + " of " + r->name + " is already taken by process " + std::to_string(expected);
+                delete r; return -1;
+            }
+            if (s->joined.load() >= world) {                      // a complete group's block that outlived its name: not ours
+                __atomic_store_n(&s->pid[rank], 0, __ATOMIC_RELEASE);
+                munmap(p, sizeof(RdvShm)); usleep(200); continue;
+            }
             r->shm = s;
-            s->pid[rank] = (int)getpid();
             break;
         }
     }

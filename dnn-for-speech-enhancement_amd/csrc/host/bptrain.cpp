@@ -73,7 +73,10 @@ static bp_window_chunk describe(const WindowChunk &w, int context)
 // sequential, so the lrand48 stream is consumed in the reference's order).
 class ChunkStream {
 public:
-    ChunkStream(bp::PfileReader &r, const bp::PfileReader::Plan &p, const std::vector<int> &order, bool shuffle, bool prefetch)
+    // pin: the slots are DMA sources (stack=device: bp_*_windows uploads straight out of them).  With stack=host they are not --
+    // expand() copies into the caller's stacked buffers -- and pinning them would lock hundreds of MB and cost the
+    // registration time for nothing.
+    ChunkStream(bp::PfileReader &r, const bp::PfileReader::Plan &p, const std::vector<int> &order, bool shuffle, bool prefetch, bool pin)
         : r_(r), p_(p), order_(order), shuffle_(shuffle), prefetch_(prefetch)
     {
         // both slots get their final capacity now and are pinned (bp_host_register): the uploads of bp_*_windows are then DMA
@@ -82,8 +85,12 @@ public:
         for (size_t c = 0; c < p.chunk_frame_st.size(); ++c) { const size_t f = (size_t)r.chunk_shape(p, (int)c).n_frames; if (f > fcap) fcap = f; }
         for (auto &s : slot_) {
             s.fea.reserve(fcap * r.fea_dim()); s.targ.reserve(fcap * r.out_dim());
-            if (fcap && bp_host_register(s.fea.data(), s.fea.capacity() * sizeof(float)) == 0) pinned_.push_back(s.fea.data());
-            if (fcap && bp_host_register(s.targ.data(), s.targ.capacity() * sizeof(float)) == 0) pinned_.push_back(s.targ.data());
+            if (!pin || !fcap) continue;
+            for (std::vector<float> *v : {&s.fea, &s.targ}) {
+                if (bp_host_register(v->data(), v->capacity() * sizeof(float)) == 0) pinned_.push_back(v->data());
+                else fprintf(stderr, "bptrain: could not pin a %zu MB read-ahead slot (%s); its uploads will be staged copies\n",
+                             v->capacity() * sizeof(float) >> 20, bp_last_error());
+            }
         }
         if (prefetch_ && !order_.empty()) start(0);
     }
@@ -94,23 +101,27 @@ public:
     }
     const WindowChunk &get(int i)
     {
+        // (a reader error found by the read-ahead thread is reported HERE, on the main thread: print + exit(0) from a helper
+        // thread would run the exit handlers while this thread is still inside the library)
+        std::string err;
         if (prefetch_) {
-            fut_.get();
-            if (i + 1 < (int)order_.size()) start(i + 1);
+            err = fut_.get();
+            if (err.empty() && i + 1 < (int)order_.size()) start(i + 1);
         } else {
-            r_.read_chunk_windows(p_, order_[i], shuffle_, slot_[i & 1]);
+            err = r_.try_read_chunk_windows(p_, order_[i], shuffle_, slot_[i & 1]);
         }
+        if (!err.empty()) bp::die("%s", err.c_str());
         return slot_[i & 1];
     }
 private:
     void start(int i)
     {
-        fut_ = std::async(std::launch::async, [this, i] { r_.read_chunk_windows(p_, order_[i], shuffle_, slot_[i & 1]); });
+        fut_ = std::async(std::launch::async, [this, i] { return r_.try_read_chunk_windows(p_, order_[i], shuffle_, slot_[i & 1]); });
     }
     bp::PfileReader &r_; const bp::PfileReader::Plan &p_; std::vector<int> order_; bool shuffle_, prefetch_;
     WindowChunk slot_[2];
     std::vector<void *> pinned_;
-    std::future<void> fut_;
+    std::future<std::string> fut_;
 };
 
 static void parse_range(const std::string &r, int *st, int *en, FILE *log)
@@ -303,14 +314,20 @@ int main(int argc, char **argv)
         // (rank 0: tables + shuffle + noise-aware rows; everyone: 1/world of the frame conversion), the main thread
         // consumes: this rank's rows of every global minibatch
         if (!P.stack_on_device && lead) fprintf(log, "(gpu_used > 1: stack=host is not used, the context windows are built on the device)\n");
+        ring->register_rank(rank);                          // (peers notice this process dying without its atexit hook)
         const bool ring_pinned = bp_host_register(ring->base(), ring->bytes()) == 0;      // (per process: after the fork)
+        if (!ring_pinned) fprintf(stderr, "bptrain: rank %d could not pin the shared chunk ring (%s); its uploads will be staged copies\n", rank, bp_last_error());
         std::thread helper([&] {
             for (int i = 0; i < nchunks; ++i)
                 if (!ring->produce(reader, tp, i, chunk_index[i], true, rank)) return;
         });
         for (int i = 0; i < nchunks; ++i) {
             bp::ChunkRing::View v;
-            if (!ring->acquire(i, v)) { printf("bptrain: the data-parallel group was aborted\n"); fflush(stdout); _exit(3); }
+            if (!ring->acquire(i, v)) {
+                const std::string why = ring->error();
+                printf("bptrain: the data-parallel group was aborted%s%s\n", why.empty() ? "" : ": ", why.c_str());
+                fflush(stdout); _exit(3);
+            }
             fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, v.n_samples);
             fflush(log);
             const std::vector<int> rows = shard_rows(v.n_samples, P.bunchsize, world, rank);
@@ -333,7 +350,7 @@ int main(int argc, char **argv)
         g_ring_finished = true;
         if (ring_pinned) bp_host_unregister(ring->base());
     } else {
-        ChunkStream chunks(reader, tp, chunk_index, true, P.prefetch);
+        ChunkStream chunks(reader, tp, chunk_index, true, P.prefetch, P.stack_on_device);
         for (int i = 0; i < nchunks; ++i) {
             const WindowChunk &w = chunks.get(i);           // (the read of chunk i+1 is now running behind us)
             fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, w.n_samples);
@@ -373,7 +390,7 @@ int main(int argc, char **argv)
     {
         std::vector<int> cv_order(cp.chunk_frame_st.size());
         for (size_t i = 0; i < cv_order.size(); ++i) cv_order[i] = (int)i;
-        ChunkStream chunks(reader, cp, cv_order, false, P.prefetch);
+        ChunkStream chunks(reader, cp, cv_order, false, P.prefetch, P.stack_on_device);
         for (int i = 0; i < (int)cv_order.size(); ++i) {
             const WindowChunk &w = chunks.get(i);
             printf("cur_chunk_samples=%d\n", w.n_samples);

@@ -11,10 +11,17 @@
 //                 into the shared slot
 //     every rank  then takes ITS rows of every global minibatch out of the shared tables and uploads
 // The result in the slot is bit-identical to PfileReader::read_chunk_windows (same pieces, tests/test_pfile_reader.py).
-// Slot i&1 is refilled while the other one trains.  A rank that dies raises `abort`, so the others fail instead of hang.
+// Slot i&1 is refilled while the other one trains.  A rank that leaves through exit() raises `abort` (atexit hook of the
+// caller); a rank that dies WITHOUT running it (SIGKILL, a crash, _exit) is noticed by its peers' waits, which poll the
+// registered pids a few times a second; and a wait that outlasts the group's time budget (BP_DP_TIMEOUT_S, the bound of
+// the device-side waits and of the rendezvous barriers, x2 + 30 s: a chunk's training may legitimately sit between two
+// waits) aborts as well.  A producer that hits a reader error leaves the text in the header for the main threads.
 #pragma once
 #include <atomic>
 #include <new>
+#include <errno.h>
+#include <signal.h>
+#include <string>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -58,10 +65,27 @@ public:
         base_ = (char *)p;
         hdr_ = new (base_) Hdr();
         hdr_->abort.store(0);
+        hdr_->err[0] = 0;
+        for (int r = 0; r < 8; ++r) hdr_->pid[r].store(0);
+        {
+            const char *e = getenv("BP_DP_TIMEOUT_S");
+            const double v = e ? atof(e) : 60.0;
+            timeout_s_ = 2.0 * (v > 0.5 ? v : 0.5) + 30.0;
+        }
         for (int s = 0; s < 2; ++s) { hdr_->slot[s].tables_seq.store(-1); hdr_->slot[s].ready_seq.store(-1); hdr_->slot[s].converted.store(0); hdr_->slot[s].consumed.store(world); }
     }
     ~ChunkRing() { if (base_) munmap(base_, bytes_); }
     void abort() { if (hdr_) hdr_->abort.store(1); }
+    // every rank, once, after the fork: lets the peers' waits notice a process that died without raising `abort`
+    void register_rank(int rank) { if (rank >= 0 && rank < 8) hdr_->pid[rank].store((int)getpid()); }
+    // first reader error a producer thread ran into (empty: none)
+    std::string error() const { char b[sizeof(hdr_->err)]; memcpy(b, hdr_->err, sizeof(b)); b[sizeof(b) - 1] = 0; return std::string(b); }
+    void fail(const std::string &msg)
+    {
+        int expected = 0;
+        if (hdr_->err_set.compare_exchange_strong(expected, 1)) { strncpy(hdr_->err, msg.c_str(), sizeof(hdr_->err) - 1); hdr_->err[sizeof(hdr_->err) - 1] = 0; }
+        hdr_->abort.store(1);
+    }
     bool aborted() const { return hdr_->abort.load() != 0; }
 
     // The producer side of chunk number `seq` of the epoch (plan chunk `chunk_index`), run by EVERY rank in order
@@ -73,24 +97,30 @@ public:
         float *fea = slot_fea(seq & 1), *targ = fea + (size_t)fcap_ * D_, *nat = targ + (size_t)fcap_ * OD_;
         int *ws = (int *)(nat + (size_t)ncap_ * D_), *tf = ws + scap_, *nr = tf + scap_;
         const PfileReader::ChunkShape c = r.chunk_shape(p, chunk_index);
-        if (c.n_frames > fcap_ || c.n_samples > scap_) die("chunk ring: chunk %d exceeds the planned capacity", chunk_index);
+        if (c.n_frames > fcap_ || c.n_samples > scap_) { fail("chunk ring: chunk " + std::to_string(chunk_index) + " exceeds the planned capacity"); return false; }
         if (rank == 0) {
             if (!wait([&] { return s.consumed.load() == world_; })) return false;       // previous tenant fully consumed
             s.converted.store(0); s.consumed.store(0);
             std::vector<int> seg_start, seg_sent;
             r.build_tables(p, chunk_index, shuffle, ws, tf, r.nat() ? nr : nullptr, seg_start, seg_sent);
-            if ((int)seg_start.size() > ncap_ && r.nat()) die("chunk ring: more noise-aware rows than planned");
+            if ((int)seg_start.size() > ncap_ && r.nat()) { fail("chunk ring: more noise-aware rows than planned"); return false; }
             s.n_samples = c.n_samples; s.n_frames = c.n_frames; s.n_nat = r.nat() ? (int)seg_start.size() : 0;
             seg_start_ = seg_start; seg_sent_ = seg_sent;
             s.tables_seq.store(seq);
         }
         if (!wait([&] { return s.tables_seq.load() == seq; })) return false;
         const int lo = (int)((long)c.n_frames * rank / world_), hi = (int)((long)c.n_frames * (rank + 1) / world_);
-        r.convert_frames(p, chunk_index, c.frame_st, lo, hi, fea, targ);
+        {   // (this runs on a helper thread: no print-and-exit in here, the text goes to the main threads through the header)
+            const std::string e = r.try_convert_frames(p, chunk_index, c.frame_st, lo, hi, fea, targ);
+            if (!e.empty()) { fail(e); return false; }
+        }
         s.converted.fetch_add(1);
         if (rank == 0) {
             if (!wait([&] { return s.converted.load() == world_; })) return false;
-            if (r.nat() && c.n_frames > 0) r.nat_rows(p, chunk_index, fea, seg_start_, seg_sent_, nat);
+            if (r.nat() && c.n_frames > 0) {
+                const std::string e = r.try_nat_rows(p, chunk_index, fea, seg_start_, seg_sent_, nat);
+                if (!e.empty()) { fail(e); return false; }
+            }
             s.ready_seq.store(seq);
         }
         return true;
@@ -113,19 +143,27 @@ public:
 
 private:
     struct Slot { std::atomic<int> tables_seq, converted, ready_seq, consumed; int n_samples, n_frames, n_nat; };
-    struct Hdr { std::atomic<int> abort; Slot slot[2]; };
+    struct Hdr { std::atomic<int> abort, err_set; std::atomic<int> pid[8]; Slot slot[2]; char err[256]; };
     float *slot_fea(int s) const { return (float *)(base_ + 4096 + (size_t)s * slot_bytes_); }
     template <class F> bool wait(F cond)
     {
-        const time_t t0 = time(nullptr);
+        struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
         for (unsigned spins = 0; !cond(); ++spins) {
             if (hdr_->abort.load()) return false;
-            if ((spins & 1023) == 1023 && time(nullptr) - t0 > 600) { hdr_->abort.store(1); return false; }   // a rank is gone
+            if ((spins & 1023) == 1023) {                        // every ~0.2 s
+                for (int r = 0; r < world_ && r < 8; ++r) {      // a registered peer that no longer exists: nobody will wake us
+                    const int pid = hdr_->pid[r].load();
+                    if (pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH) { fail("chunk ring: rank " + std::to_string(r) + " (process " + std::to_string(pid) + ") is gone"); return false; }
+                }
+                struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s_) { fail("chunk ring: timed out waiting for a peer"); return false; }
+            }
             usleep(spins < 64 ? 20 : 200);
         }
         return true;
     }
     int world_, fcap_, scap_, ncap_, D_, OD_;
+    double timeout_s_ = 150.0;
     size_t slot_floats_, slot_bytes_, bytes_;
     char *base_ = nullptr;
     Hdr *hdr_ = nullptr;

@@ -4,7 +4,9 @@
 
 #include <thread>
 
+#include <errno.h>
 #include <stdarg.h>
+#include <string>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -164,19 +166,25 @@ void PfileReader::rand_index(int *vec, int len)
 // Byte-swap / normalisation of a chunk's records is per-frame independent: split the rows over a few threads
 // (a 102400-frame chunk is 2 x 106 MB of records; one thread converts ~0.5 G floats/s, the GPU consumes a chunk
 // in 90 ms).  Element-wise work only, so the result does not depend on the split.
+// A worker never calls die() (= printf + exit(0)): two workers failing together would run exit() concurrently, which is
+// undefined behaviour, and atexit handlers would run while the siblings still write into the shared slot.
+// body(lo, hi) returns an error text (empty = fine); the first one is handed back to the CALLING thread after the join.
 template <class F>
-static void parallel_rows(int n, F body)
+static std::string parallel_rows(int n, F body)
 {
     unsigned hw = std::thread::hardware_concurrency();
     int nt = (int)(hw > 8 ? 8 : (hw < 1 ? 1 : hw));
     if (n < 4096) nt = 1;
-    if (nt == 1) { body(0, n); return; }
+    if (nt == 1) return body(0, n);
     std::vector<std::thread> th;
+    std::vector<std::string> err((size_t)nt);
     for (int t = 0; t < nt; ++t) {
         const int lo = (int)((long)n * t / nt), hi = (int)((long)n * (t + 1) / nt);
-        th.emplace_back([=, &body] { body(lo, hi); });
+        th.emplace_back([=, &body, &err] { err[(size_t)t] = body(lo, hi); });
     }
     for (auto &t : th) t.join();
+    for (auto &e : err) if (!e.empty()) return e;
+    return std::string();
 }
 
 int PfileReader::WindowChunk::n_nat() const { return fea_dim > 0 ? (int)(nat.size() / (size_t)fea_dim) : 0; }
@@ -204,14 +212,21 @@ PfileReader::ChunkShape PfileReader::chunk_shape(const Plan &p, int ci) const
     return c;
 }
 
-static void pread_all(FILE *fp, void *dst, size_t bytes, long off, const char *what, int ci)
+// positioned read of exactly `bytes`; an interrupted call is retried, a short file is an error text (empty = fine)
+static std::string pread_all(FILE *fp, void *dst, size_t bytes, long off, const char *what, int ci)
 {
     char *d = (char *)dst;
     while (bytes > 0) {
         const ssize_t n = pread(fileno(fp), d, bytes, off);
-        if (n <= 0) die("%s pfile: short read in chunk %d.", what, ci);
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) {
+            char msg[160];
+            snprintf(msg, sizeof(msg), "%s pfile: short read in chunk %d (%s).", what, ci, n == 0 ? "file ends before the frames its header promises" : strerror(errno));
+            return msg;
+        }
         d += n; off += n; bytes -= (size_t)n;
     }
+    return std::string();
 }
 
 // frames [lo, hi) of the chunk that starts at file frame frame_st: big-endian records {sent_id, frame_id, feat[D]} ->
@@ -219,21 +234,31 @@ static void pread_all(FILE *fp, void *dst, size_t bytes, long off, const char *w
 // Positioned reads only (no shared file offset): several threads / forked processes may convert slices at once.
 void PfileReader::convert_frames(const Plan &p, int ci, int frame_st, int lo, int hi, float *fea, float *targ) const
 {
+    const std::string err = try_convert_frames(p, ci, frame_st, lo, hi, fea, targ);
+    if (!err.empty()) die("%s", err.c_str());                     // from the calling thread, after every worker has been joined
+}
+
+std::string PfileReader::try_convert_frames(const Plan &p, int ci, int frame_st, int lo, int hi, float *fea, float *targ) const
+{
     const int D = cfg_.fea_dim, OD = cfg_.out_dim, n = hi - lo;
-    if (n <= 0) return;
+    if (n <= 0) return std::string();
     // every worker reads AND converts its own rows: the copy out of the page cache (2 x 105 MB for a 102400-frame chunk
     // of 257-bin frames) is as expensive as the arithmetic, and a single positioned read of the whole chunk made it the
     // serial part of the reader (1.0 M frames/s end to end against 1.16 M for the GPU alone, round 2)
-    parallel_rows(n, [&](int a, int b) {
+    return parallel_rows(n, [&](int a, int b) -> std::string {
         std::vector<uint32_t> raw((size_t)(b - a) * (D + 2));
-        pread_all(fp_data_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo + a) * (long)sizeof(float) * (D + 2), "data", ci);
+        std::string e = pread_all(fp_data_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo + a) * (long)sizeof(float) * (D + 2), "data", ci);
+        if (!e.empty()) return e;
         if (lo + a == 0) {
             const int first_sent = (int)bswap(raw[0]);          // only the first record's sentence id is used (Interface.cc:740-741)
             // The id indexes the sentence table.  The reference trusts it; a corrupt or mismatched Pfile would make us read
             // outside the table (or silently build wrong windows), so it must lie in the planned range and own the chunk's first frame.
             if (first_sent < p.sent_st || first_sent > p.sent_en || first_sent >= (int)total_sents_ || frames_before_sent_[first_sent] <= frame_st ||
-                (first_sent > 0 && frames_before_sent_[first_sent - 1] > frame_st))
-                die("data pfile: record %d carries sentence id %d, which does not contain that frame (sentences %d-%d planned).", frame_st, first_sent, p.sent_st, p.sent_en);
+                (first_sent > 0 && frames_before_sent_[first_sent - 1] > frame_st)) {
+                char msg[200];
+                snprintf(msg, sizeof(msg), "data pfile: record %d carries sentence id %d, which does not contain that frame (sentences %d-%d planned).", frame_st, first_sent, p.sent_st, p.sent_en);
+                return msg;
+            }
         }
         for (int i = a; i < b; ++i)
             for (int j = 0; j < D; ++j) {
@@ -243,14 +268,16 @@ void PfileReader::convert_frames(const Plan &p, int ci, int frame_st, int lo, in
                 v *= dvar_[j];
                 fea[(size_t)(lo + i) * D + j] = v;
             }
-        if (!targ) return;
+        if (!targ) return std::string();
         raw.resize((size_t)(b - a) * (OD + 2));
-        pread_all(fp_targ_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo + a) * (long)sizeof(float) * (OD + 2), "targ", ci);
+        e = pread_all(fp_targ_, raw.data(), raw.size() * 4, PFILE_HEADER_SIZE + (long)(frame_st + lo + a) * (long)sizeof(float) * (OD + 2), "targ", ci);
+        if (!e.empty()) return e;
         for (int i = a; i < b; ++i)
             for (int j = 0; j < OD; ++j) {
                 const uint32_t x = bswap(raw[(size_t)(i - a) * (OD + 2) + 2 + j]);
                 memcpy(&targ[(size_t)(lo + i) * OD + j], &x, 4);
             }
+        return std::string();
     });
 }
 
@@ -303,6 +330,12 @@ void PfileReader::build_tables(const Plan &p, int ci, bool shuffle, int *win_sta
 // and divided by 6.0f (Interface.cc:776-779, generalised from the literal 129 to fea_dim)
 void PfileReader::nat_rows(const Plan &p, int ci, const float *fea, const std::vector<int> &seg_start, const std::vector<int> &seg_sent, float *nat) const
 {
+    const std::string err = try_nat_rows(p, ci, fea, seg_start, seg_sent, nat);
+    if (!err.empty()) die("%s", err.c_str());
+}
+
+std::string PfileReader::try_nat_rows(const Plan &p, int ci, const float *fea, const std::vector<int> &seg_start, const std::vector<int> &seg_sent, float *nat) const
+{
     const ChunkShape c = chunk_shape(p, ci);
     const int D = cfg_.fea_dim, frames_need = c.n_frames;
     const bool inference = !p.chunk_frame_en.empty();
@@ -314,7 +347,8 @@ void PfileReader::nat_rows(const Plan &p, int ci, const float *fea, const std::v
             // SENTENCE's first 6 frames, which lie before this chunk -- fetch and normalise just those
             const int nf = std::min(6, frames_before_sent_[cur_sent] - sent_begin);
             std::vector<uint32_t> head((size_t)nf * (D + 2));
-            pread_all(fp_data_, head.data(), head.size() * 4, PFILE_HEADER_SIZE + (long)sent_begin * (long)sizeof(float) * (D + 2), "data", ci);
+            const std::string e = pread_all(fp_data_, head.data(), head.size() * 4, PFILE_HEADER_SIZE + (long)sent_begin * (long)sizeof(float) * (D + 2), "data", ci);
+            if (!e.empty()) return e;
             for (int k = 0; k < D; ++k) {
                 float sacc = 0.0f;
                 for (int f = 0; f < 6; ++f) {
@@ -337,9 +371,17 @@ void PfileReader::nat_rows(const Plan &p, int ci, const float *fea, const std::v
             nrow[k] = s / 6.0f;
         }
     }
+    return std::string();
 }
 
 int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowChunk &w)
+{
+    const std::string err = try_read_chunk_windows(p, ci, shuffle, w);
+    if (!err.empty()) die("%s", err.c_str());
+    return w.n_samples;
+}
+
+std::string PfileReader::try_read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowChunk &w)
 {
     const int D = cfg_.fea_dim, OD = cfg_.out_dim;
     const ChunkShape c = chunk_shape(p, ci);
@@ -351,15 +393,16 @@ int PfileReader::read_chunk_windows(const Plan &p, int ci, bool shuffle, WindowC
     std::vector<int> seg_start, seg_sent;
     // (tables first: the shuffle consumes lrand48 before any file access, as Readchunk does, Interface.cc:700-704)
     build_tables(p, ci, shuffle, w.win_start.data(), w.targ_frame.data(), nat_ ? w.nat_row.data() : nullptr, seg_start, seg_sent);
-    if (c.n_frames <= 0) return w.n_samples;
+    if (c.n_frames <= 0) return std::string();
     w.fea.resize((size_t)c.n_frames * D);
     w.targ.resize((size_t)c.n_frames * OD);
-    convert_frames(p, ci, c.frame_st, 0, c.n_frames, w.fea.data(), w.targ.data());
+    std::string err = try_convert_frames(p, ci, c.frame_st, 0, c.n_frames, w.fea.data(), w.targ.data());
+    if (!err.empty()) return err;
     if (nat_) {
         w.nat.resize(seg_start.size() * (size_t)D);
-        nat_rows(p, ci, w.fea.data(), seg_start, seg_sent, w.nat.data());
+        err = try_nat_rows(p, ci, w.fea.data(), seg_start, seg_sent, w.nat.data());
     }
-    return w.n_samples;
+    return err;
 }
 
 void PfileReader::expand(const WindowChunk &w, float *in, float *targ) const

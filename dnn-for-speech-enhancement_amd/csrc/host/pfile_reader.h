@@ -60,15 +60,20 @@ public:
         int fea_dim = 0;
     };
     int read_chunk_windows(const Plan &p, int chunk_index, bool shuffle, WindowChunk &out);
+    // The same without the print-and-exit convention, for callers that run on a helper thread (a read-ahead thread, the
+    // shared ring's producer): the error text comes back (empty = fine) and the MAIN thread decides how to leave.
+    std::string try_read_chunk_windows(const Plan &p, int chunk_index, bool shuffle, WindowChunk &out);
     // The same in pieces (read_chunk_windows is their composition), for a node-level shared reader (chunk_ring.h):
     // tables once, frame conversion in slices by whoever has cores to spare.  convert_frames / nat_rows use positioned
     // reads only and may run concurrently in several threads or forked processes.
     struct ChunkShape { int frame_st = 0, n_frames = 0, n_samples = 0; };
     ChunkShape chunk_shape(const Plan &p, int chunk_index) const;
     void convert_frames(const Plan &p, int chunk_index, int frame_st, int lo, int hi, float *fea, float *targ) const;
+    std::string try_convert_frames(const Plan &p, int chunk_index, int frame_st, int lo, int hi, float *fea, float *targ) const;
     void build_tables(const Plan &p, int chunk_index, bool shuffle, int *win_start, int *targ_frame, int *nat_row,
                       std::vector<int> &seg_start, std::vector<int> &seg_sent);
     void nat_rows(const Plan &p, int chunk_index, const float *fea, const std::vector<int> &seg_start, const std::vector<int> &seg_sent, float *nat) const;
+    std::string try_nat_rows(const Plan &p, int chunk_index, const float *fea, const std::vector<int> &seg_start, const std::vector<int> &seg_sent, float *nat) const;
     int fea_dim() const { return cfg_.fea_dim; }
     int out_dim() const { return cfg_.out_dim; }
     // host-side expansion of a window chunk into stacked rows (what Interface::Readchunk leaves in its buffers)

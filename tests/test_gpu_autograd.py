@@ -72,11 +72,16 @@ def test_full_size_gradient_matches_torch_float64_autograd(pkg, ls, drop):
     assert all(v < TOL for v in worst.values()), worst
 
 
-def test_bf16_gradient_matches_torch_float64_autograd(pkg):
-    """compute_dtype = 1 (bf16 GEMM operands, fp32 accumulation; BASELINE.json configs[4]'s arithmetic) against the same
-    oracle-free reference at bf16's bar of 2e-2.  Rms over each tensor: under bf16 single gradient elements move by a few per
-    cent of the largest when a rounding / ReLU boundary falls differently, the tensor as a whole does not."""
+def test_bf16_gradient_matches_an_oracle_free_bf16_reference(pkg):
+    """compute_dtype = 1 (bf16 GEMM operands, fp32 accumulation; BASELINE.json configs[4]'s arithmetic) at bf16's bar of 2e-2
+    against a reference that shares nothing with oracle/: the bunch written out by hand in numpy float64 with bf16 rounding at
+    the points where the device stores bf16 (tests/torch_ref.py bf16_grads; pinned on the CPU against the oracle's bf16 mode).
+    Rms over each tensor: under bf16 single gradient elements move by a few per cent of the largest when a rounding / ReLU
+    boundary falls differently, the tensor as a whole does not.  Against EXACT arithmetic (torch float64 autograd of the same
+    loss) the bf16 gradient is 4-6 % off in the lower layers -- measured and printed here, it is what bf16 storage costs,
+    not a defect -- so that figure only has to show that the device really computes in bf16."""
     pytest.importorskip("torch")
+    from torch_ref import bf16_grads
     ls, B, seed = [2827, 1024, 1024, 257], 256, 5
     W, b = pkg.glorot_net(ls, seed=2, beta=0.5)
     rng = np.random.default_rng(7)
@@ -88,10 +93,14 @@ def test_bf16_gradient_matches_torch_float64_autograd(pkg):
     gw, gb = g.read_grads()
     g.close()
     masks = [drop_mask(seed, 0, l, B, ls[l], 0.1 if l == 0 else 0.2) for l in range(len(ls) - 1)]
+    rw, rb, _, _ = bf16_grads(ls, W, b, x, t, masks)
     tw, tb, _, _ = torch_grads(ls, W, b, x, t, masks)
     rms = lambda a, r: float(np.sqrt(((np.asarray(a, np.float64) - r) ** 2).sum() / max((r ** 2).sum(), 1e-300)))
-    worst = {}
+    worst, exact = {}, {}
     for l in range(1, len(ls)):
-        worst["W%d" % l], worst["b%d" % l] = rms(gw[l], tw[l]), rms(gb[l], tb[l])
-    print("bf16 gradient vs torch float64 autograd (rms):", {k: "%.1e" % v for k, v in worst.items()})
-    assert all(1e-5 < v < 2e-2 for v in worst.values()), worst      # (and it really is a bf16 computation)
+        worst["W%d" % l], worst["b%d" % l] = rms(gw[l], rw[l]), rms(gb[l], rb[l])
+        exact["W%d" % l] = rms(gw[l], tw[l])
+    print("bf16 gradient vs the hand-written bf16 reference (rms):", {k: "%.1e" % v for k, v in worst.items()})
+    print("bf16 gradient vs exact arithmetic, torch float64 autograd (rms):", {k: "%.1e" % v for k, v in exact.items()})
+    assert all(v < 2e-2 for v in worst.values()), worst
+    assert all(1e-4 < v < 0.15 for v in exact.values()), exact      # it really is a bf16 computation, and not a broken one

@@ -217,3 +217,23 @@ def test_torch_reference_of_the_gpu_backward_test_equals_oracle_gradient(oracle_
     rw, rb, _, _ = torch_grads(ls, W, b, xs, ts, ms, act=act)
     for l in range(1, len(ls)):
         assert relerr(kw[l], tw[l] - rw[l] * (2.0 / B)) < 1e-9, l
+
+
+def test_hand_written_bf16_reference_equals_the_oracle_bf16_mode(oracle_mod):
+    """tests/torch_ref.py bf16_grads (numpy float64 with bf16 storage rounding, the reference of the oracle-free bf16 GPU
+    test) against the oracle's compute_dtype = 1 gradient with the same masks."""
+    from torch_ref import bf16_grads, bf16_round
+    assert np.array_equal(bf16_round(np.array([1.0, 1.00390625, 1.01171875, -3.140625], np.float32)), [1.0, 1.0, 1.015625, -3.140625])
+    ls, B = [70, 96, 64, 33], 48
+    W, b = N.glorot_net(ls, seed=4, beta=1.5)
+    rng = np.random.default_rng(8)
+    b = [None] + [rng.normal(size=ls[l]).astype(np.float32) * 0.2 for l in range(1, len(ls))]
+    x = rng.normal(size=(B, ls[0])).astype(np.float32)
+    t = rng.normal(size=(B, ls[-1])).astype(np.float32)
+    o = oracle_mod.Oracle(ls, B, weights=W, bias=b, compute_dtype=1, acc_double=True, dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=9)
+    masks = [o.fill_mask(0, l, B) for l in range(len(ls) - 1)]
+    gw, gb, ys, out = o.grads(x, t, masks=masks)
+    rw, rb, rys, rout = bf16_grads(ls, W, b, x, t, masks)
+    assert relerr(out, rout) < 1e-5
+    for l in range(1, len(ls)):
+        assert relerr(gw[l], rw[l]) < 2e-3 and relerr(gb[l], rb[l]) < 2e-3, (l, relerr(gw[l], rw[l]), relerr(gb[l], rb[l]))

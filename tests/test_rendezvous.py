@@ -88,3 +88,33 @@ def test_argument_errors(pkg):
     r = pkg.Rendezvous("t-rdv-solo-%d" % os.getpid(), 1, 0, timeout_s=1.0)   # a one-rank group is legal
     assert r.allgather_f64(3.0) == [3.0]
     r.close()
+
+
+def test_a_second_job_cannot_take_over_the_key_of_a_job_that_is_still_joining(pkg):
+    """rank 0 used to unlink whatever carried the name; a second job started with the same key would then
+    capture the first job's late ranks.  Now the second creator is refused while the first block's creator is alive."""
+    key = "t-rdv-live-%d" % os.getpid()
+    p0 = _spawn(key, 2, 0, timeout_s=15.0)                       # job A, waiting for its rank 1
+    deadline = time.time() + 10
+    while not os.path.exists("/dev/shm/bpdp-" + key) and time.time() < deadline:
+        time.sleep(0.05)
+    time.sleep(0.2)
+    q0 = _spawn(key, 2, 0, timeout_s=3.0)                        # job B, same key
+    oq = q0.communicate(timeout=60)[0]
+    assert q0.returncode != 0 and "live job" in oq, oq
+    p1 = _spawn(key, 2, 1, timeout_s=15.0)                       # job A's late rank still finds job A
+    o0, o1 = p0.communicate(timeout=60)[0], p1.communicate(timeout=60)[0]
+    assert p0.returncode == 0 and p1.returncode == 0, (o0, o1)
+    assert "OK 0" in o0 and "OK 1" in o1
+
+
+def test_duplicate_rank_is_an_error(pkg):
+    key = "t-rdv-dup-%d" % os.getpid()
+    p0 = _spawn(key, 3, 0, timeout_s=4.0)
+    p1 = _spawn(key, 3, 1, timeout_s=4.0)
+    time.sleep(1.0)
+    d1 = _spawn(key, 3, 1, timeout_s=4.0)                        # a second process claiming rank 1
+    od = d1.communicate(timeout=60)[0]
+    assert d1.returncode != 0 and "already taken" in od, od
+    p0.communicate(timeout=60); p1.communicate(timeout=60)       # (rank 2 never comes: they time out)
+    assert p0.returncode != 0 and p1.returncode != 0

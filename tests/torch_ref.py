@@ -36,3 +36,39 @@ def torch_grads(ls, W, b, x, t, masks=None, keep_rows=None, act=0):
     gw = [None] + [Wt[l].grad.numpy() for l in range(1, L)]
     gb = [None] + [bt[l].grad.numpy() for l in range(1, L)]
     return gw, gb, ys, out.detach().numpy()
+
+
+def bf16_round(a):
+    """fp32 -> bf16 (round to nearest even) -> back, as float64 values: the storage rounding of compute_dtype = 1
+    (dnn-for-speech-enhancement_amd/csrc/bp_bf16.h f2bf)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + np.uint64(0x7FFF) + ((u >> np.uint64(16)) & np.uint64(1))) & np.uint64(0xFFFF0000)
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def bf16_grads(ls, W, b, x, t, masks=None):
+    """The same bunch with bf16 STORAGE of everything a GEMM reads and exact (float64) arithmetic in between -- written
+    out by hand (forward, dEdX_L = (2/B)(out - t), dEdX_{l-1} = (y_{l-1} > 0) * dEdX_l . W_l^T, G_l = y_{l-1}^T . dEdX_l),
+    because the rounding of the back-propagated errors is not something autograd can express.  Rounded to bf16, as on the
+    device: the masked input, every hidden output, every dEdX_l, the weights; NOT rounded: out, the bias, the sums.  ReLU."""
+    L, B = len(ls), x.shape[0]
+    Wb = [None] + [bf16_round(W[l]) for l in range(1, L)]
+    h = np.asarray(x, np.float64)
+    if masks is not None and masks[0] is not None:
+        h = h * (1.0 - masks[0])
+    ys = [bf16_round(h)]
+    for l in range(1, L):
+        z = ys[l - 1] @ Wb[l] + np.asarray(b[l], np.float64)
+        if l < L - 1:
+            y = np.maximum(z, 0.0)
+            if masks is not None and masks[l] is not None:
+                y = y * (1.0 - masks[l])
+            ys.append(bf16_round(y))
+        else:
+            out = z
+    dx = {L - 1: bf16_round((2.0 / B) * (out - np.asarray(t, np.float64)))}
+    for l in range(L - 1, 1, -1):
+        dx[l - 1] = bf16_round((ys[l - 1] > 0) * (dx[l] @ Wb[l].T))
+    gw = [None] + [ys[l - 1].T @ dx[l] for l in range(1, L)]
+    gb = [None] + [dx[l].sum(0) for l in range(1, L)]
+    return gw, gb, ys, out
