@@ -49,8 +49,23 @@ static void read_tail(FILE *fp, long offset, unsigned nsent, std::vector<int> &o
     for (unsigned i = 0; i < nsent; ++i) out[i] = (int)bswap((uint32_t)out[i]);
 }
 
+// The reference trusts the sentence table; every chunk's frame range is computed from it, so a corrupt one would size
+// buffers and file offsets from garbage.  It must be non-decreasing, non-negative and end on the header's frame count.
+static void check_tail(const std::vector<int> &t, unsigned total_frames, const char *what)
+{
+    int prev = 0;
+    for (size_t i = 0; i < t.size(); ++i) {
+        if (t[i] < prev || (unsigned)t[i] > total_frames) die("%s pfile tail is Not correct (sentence %zu ends at frame %d of %u).", what, i, t[i], total_frames);
+        prev = t[i];
+    }
+    if (!t.empty() && (unsigned)t.back() != total_frames) die("%s pfile tail is Not correct (the last sentence ends at frame %d, the header promises %u).", what, t.back(), total_frames);
+}
+
 PfileReader::PfileReader(const ReaderConfig &cfg) : cfg_(cfg)
 {
+    if (cfg_.fea_dim < 1 || cfg_.fea_context < 1 || cfg_.out_dim < 1 || cfg_.traincache < 1 || cfg_.fea_dim > (1 << 20) || cfg_.fea_context > (1 << 12))
+        die("fea_dim, fea_context, traincache and the layer sizes must be positive (fea_dim %d, fea_context %d, output %d, traincache %d).",
+            cfg_.fea_dim, cfg_.fea_context, cfg_.out_dim, cfg_.traincache);
     // the reference demands layersizes[0] == fea_dim*ctx + fea_dim (NAT hard-wired, Interface.cc:395-399); the
     // original check fea_dim*ctx is kept as the NAT-off mode
     if (cfg_.input_dim == cfg_.fea_dim * (cfg_.fea_context + 1)) nat_ = true;
@@ -83,8 +98,10 @@ void PfileReader::open()
     if (fread(header.data(), PFILE_HEADER_SIZE, 1, fp_data_) != 1) die("Failed to read data pfile header.");
     total_sents_ = header_uint(header.data(), "-num_sentences");
     total_frames_ = header_uint(header.data(), "-num_frames");
+    if (total_sents_ < 1 || total_sents_ > (1u << 28) || total_frames_ > (1u << 30)) die("pfile header: implausible sentence / frame count (%u / %u).", total_sents_, total_frames_);
     read_tail(fp_data_, (long)total_frames_ * (long)sizeof(float) * (2 + cfg_.fea_dim) + PFILE_HEADER_SIZE, total_sents_,
               frames_before_sent_);
+    check_tail(frames_before_sent_, total_frames_, "data");
     if (fseek(fp_targ_, 0, SEEK_SET) != 0 || fread(header.data(), PFILE_HEADER_SIZE, 1, fp_targ_) != 1)
         die("Failed to read target pfile header.");
     const unsigned ts = header_uint(header.data(), "-num_sentences"), tf = header_uint(header.data(), "-num_frames");
