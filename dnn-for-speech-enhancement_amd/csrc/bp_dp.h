@@ -89,6 +89,35 @@ __global__ void bp_dp_wait_n(const unsigned *flags, DpIdx bases, int world, unsi
     }
 }
 
+// Exchange stream, per layer: (1) wait until the local weight-gradient launch has counted `target` tiles of this layer's
+// segment (EpiArgs::done, bp_wgrad_dma.h; signed distance, the counter only grows), (2) tell every rank, (3) wait for every
+// rank.  One wave, one launch -- it replaces an event record on the main stream (which cost it a ~7 us bubble), a
+// stream-wait, a signal kernel and a wait kernel.
+__global__ void bp_dp_sync(const unsigned *done, unsigned target, DpPeers peers, const unsigned *flags, int world, int sig_index, int wait_base,
+                           unsigned epoch, unsigned long long budget_ticks, unsigned *err, unsigned code)
+{
+    const int p = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    if (p == 0 && done) {
+        for (;;) {
+            const unsigned v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(v - target) >= 0) break;
+            if (wall_clock64() - t0 > budget_ticks) { atomicExch(err, 4000u + 1u); break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __builtin_amdgcn_s_barrier();          // (one wave: orders lane 0's poll in front of the other lanes' stores)
+    if (p < world) {
+        __hip_atomic_store(peers.flags[p] + sig_index, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (;;) {
+            const unsigned v = __hip_atomic_load(flags + wait_base + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(v - epoch) >= 0) break;
+            if (wall_clock64() - t0 > budget_ticks) { atomicExch(err, code * 1000u + (unsigned)p + 1u); break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+}
+
 struct DpReduceArgs {
     const float *grads[BP_DP_MAXRANKS];   // every rank's flat gradient buffer (own entry = local pointer)
     float *params[BP_DP_MAXRANKS];        // every rank's flat parameter arena
@@ -241,6 +270,16 @@ __global__ void bp_dp_probe_fill(float *probe, unsigned round, unsigned rank)
 {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < BP_DP_PROBE_FLOATS; i += gridDim.x * blockDim.x)
         probe[i] = bp_probe_value(round, rank, i);
+}
+// the same fill with the product's IN-KERNEL hand-off (bp_wgrad_dma.h, EpiArgs::done): plain stores, every wave drains, one
+// lane per workgroup counts -- no kernel boundary between these stores and the readers
+__global__ __launch_bounds__(256) void bp_dp_probe_fill_count(float *probe, unsigned round, unsigned rank, unsigned *done)
+{
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < BP_DP_PROBE_FLOATS; i += gridDim.x * blockDim.x)
+        probe[i] = bp_probe_value(round, rank, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // reader: system-scope 16-byte loads of slice `rank` of every rank's fine-grained probe (the reduce-scatter read)
 __global__ void bp_dp_probe_check_remote(DpReduceArgs a, unsigned round, unsigned *bad)

@@ -1166,6 +1166,9 @@ struct bp_dp {
     float *probe_p, *probe_g;     // self-test probes: ordinary (like the parameter arena) / fine-grained (like the gradient buffer)
     unsigned *flags;              // own flag words (fine-grained device memory, exported)
     unsigned *arrive;             // [BP_MAXLAYER] last-arriver counters of bp_dp_reduce_update
+    unsigned *done;               // [BP_MAXLAYER] tiles of layer l's gradient segment stored so far (counted by the wgrad-store kernel itself)
+    unsigned done_target[BP_MAXLAYER];   // host: value done[l] reaches when the current minibatch's tiles are in
+    bool counters_ok;             // the in-kernel hand-off passed the attach-time self-test (else: event + kernel boundary per group of layers)
     unsigned *err;                // pinned host word the wait kernels raise on timeout
     hipStream_t comm;             // exchange stream: signal -> wait -> reduce/update/all-gather per layer
     hipEvent_t ev_g[BP_MAXLAYER]; // main stream: gradient segment l is complete
@@ -1204,7 +1207,7 @@ static void dp_release(bp_handle *h, bool failed)
     if (d->ev_comm) (void)hipEventDestroy(d->ev_comm);
     if (d->comm) (void)hipStreamDestroy(d->comm);
     if (d->grad_fine) { if (h->grad == d->grad_fine) h->grad = d->grad_prev; (void)hipFree(d->grad_fine); }
-    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red})
+    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->done, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red})
         if (q) (void)hipFree(q);
     if (d->err) (void)hipHostFree(d->err);
     rdv_close(d->rdv, failed);
@@ -1235,13 +1238,13 @@ static DpPeers dp_peers(const bp_dp *d)
 
 // Attach-time check of the memory-model contract on the group's real devices (bp_dp.h, "attach-time self-test").
 // Returns the number of mismatching words seen by THIS rank over all rounds (W direction in *bad_w, G in *bad_g).
-static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad_w, unsigned *bad_g)
+static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad_w, unsigned *bad_g, unsigned *bad_c)
 {
     bp_dp *d = h->dp;
     unsigned *cnt = nullptr;
     float *sink = nullptr;
-    HIPCHK(hipHostMalloc((void **)&cnt, 2 * sizeof(unsigned), hipHostMallocMapped));
-    cnt[0] = cnt[1] = 0u;
+    HIPCHK(hipHostMalloc((void **)&cnt, 3 * sizeof(unsigned), hipHostMallocMapped));
+    cnt[0] = cnt[1] = cnt[2] = 0u;
     HIPCHK(hipMalloc((void **)&sink, 64));
     const DpPeers peers = dp_peers(d);
     DpReduceArgs a; memset(&a, 0, sizeof(a));
@@ -1275,8 +1278,23 @@ static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad
         HIPCHK(hipStreamSynchronize(d->comm));
         if (*(volatile unsigned *)d->err) { rc = fail(BP_ERR_STATE, "data-parallel self-test: a peer's flag never arrived"); break; }
         if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }    // nobody refills a probe a peer still reads
+        // ---- (C): the same direction with the step's IN-KERNEL hand-off -- the filling kernel counts its own workgroups, the
+        // exchange stream's bp_dp_sync (already queued, running beside it) sees the count, tells the peers, the peers read.
+        // No event and no kernel boundary between the stores and the readers' flag.
+        if (d->counters_ok) {
+            const unsigned ep2 = ep + 0x4000u;                     // (flag words only grow; probe word 2 is this direction's)
+            hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + BP_MAXLAYER, (ep_base + (unsigned)r) * 64u, peers, d->flags, d->world,
+                               bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, d->rank), bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, 0), ep2, d->budget_ticks, d->err, 3u);
+            hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r + 100u, cnt + 2);
+            hipLaunchKernelGGL(bp_dp_probe_fill_count, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r + 100u, (unsigned)d->rank, d->done + BP_MAXLAYER);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipStreamSynchronize(d->comm));
+            if (*(volatile unsigned *)d->err) { rc = fail(BP_ERR_STATE, "data-parallel self-test: the in-kernel hand-off never completed"); break; }
+            if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }
+        }
     }
-    *bad_w = cnt[0]; *bad_g = cnt[1];
+    *bad_w = cnt[0]; *bad_g = cnt[1]; *bad_c = cnt[2];
     (void)hipHostFree(cnt); (void)hipFree(sink);
     return rc;
 }
@@ -1335,6 +1353,9 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     DK(hipMemset(d->flags, 0, BP_DP_FLAG_WORDS * sizeof(unsigned)));
     DK(hipMalloc((void **)&d->arrive, BP_MAXLAYER * sizeof(unsigned)));
     DK(hipMemset(d->arrive, 0, BP_MAXLAYER * sizeof(unsigned)));
+    DK(hipMalloc((void **)&d->done, (BP_MAXLAYER + 1) * sizeof(unsigned)));       // (+1: the self-test's counter)
+    DK(hipMemset(d->done, 0, (BP_MAXLAYER + 1) * sizeof(unsigned)));
+    d->counters_ok = transport != BP_DP_TRANSPORT_RCCL && getenv("BP_DP_NO_COUNTERS") == nullptr;
     DK(hipMalloc((void **)&d->probe_p, BP_DP_PROBE_FLOATS * sizeof(float)));
     DK(hipMemset(d->probe_p, 0, BP_DP_PROBE_FLOATS * sizeof(float)));
     if (hipExtMallocWithFlags((void **)&d->probe_g, BP_DP_PROBE_FLOATS * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
@@ -1418,12 +1439,13 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
         // ---- the memory-model contract of the native exchange, checked on these devices before anything relies on it
         for (int mode = 0; mode < 2; ++mode) {
             d->acquire_mode = mode;
-            unsigned bw = 0, bg = 0;
-            DR(dp_selftest(h, 4, 4u * (unsigned)mode, &bw, &bg));
-            unsigned mine2[2] = {bw, bg}, all[2 * BP_DP_MAXRANKS];
+            unsigned bw = 0, bg = 0, bc = 0;
+            DR(dp_selftest(h, 4, 4u * (unsigned)mode, &bw, &bg, &bc));
+            unsigned mine2[3] = {bw, bg, bc}, all[3 * BP_DP_MAXRANKS];
             if (rdv_allgather(d->rdv, mine2, sizeof(mine2), all) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }
-            unsigned tw = 0, tg = 0;
-            for (int p = 0; p < world; ++p) { tw += all[2 * p]; tg += all[2 * p + 1]; }
+            unsigned tw = 0, tg = 0, tc = 0;
+            for (int p = 0; p < world; ++p) { tw += all[3 * p]; tg += all[3 * p + 1]; tc += all[3 * p + 2]; }
+            if (tc) d->counters_ok = false;                        // (every rank sees the same verdict) the event + kernel-boundary hand-off stays
             if (tg) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: self-test failed: peers read stale gradient words from a fine-grained buffer (" + std::to_string(tg) + " words)"); }
             if (!tw) break;
             if (mode == 1) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: self-test failed: stale weights after a peer's write-through stores even with an explicit acquire (" + std::to_string(tw) + " words)"); }
@@ -1479,6 +1501,24 @@ static int dp_update_grid(const DpReduceArgs &a)
     return grid < 1 ? 1 : grid;                                // (an empty slice still raises its flag)
 }
 
+// comm stream: reduce this rank's slice of layer l over all ranks, update it, write the new weights to every rank (native transport)
+static hipError_t dp_reduce_layer(bp_handle *h, int l)
+{
+    bp_dp *d = h->dp;
+    DpReduceArgs a;
+    dp_update_args(h, l, a);
+    for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
+    const int grid = dp_update_grid(a);
+    switch (d->world) {
+    case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    case 4: hipLaunchKernelGGL(bp_dp_reduce_update<4>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    case 8: hipLaunchKernelGGL(bp_dp_reduce_update<8>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    default: hipLaunchKernelGGL(bp_dp_reduce_update<0>, dim3(grid), dim3(256), 0, d->comm, a); break;
+    }
+    return hipGetLastError();
+}
+
 // comm stream, after the gradient segments of layers ls[0..n) are complete on the main stream (ONE event: every event
 // record costs the main stream a ~6 us bubble, profiles/r03_dp_world1_timeline.txt): tell every rank, wait for every
 // rank's segments, then per layer reduce this rank's slice, update it and write the new weights to every rank
@@ -1516,16 +1556,7 @@ static hipError_t dp_exchange_layers(bp_handle *h, const int *ls, int n)
             if ((er = hipEventRecord(d->ev_w[l], d->comm)) != hipSuccess) return er;
             continue;
         }
-        for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
-        const int grid = dp_update_grid(a);
-        switch (d->world) {
-        case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
-        case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
-        case 4: hipLaunchKernelGGL(bp_dp_reduce_update<4>, dim3(grid), dim3(256), 0, d->comm, a); break;
-        case 8: hipLaunchKernelGGL(bp_dp_reduce_update<8>, dim3(grid), dim3(256), 0, d->comm, a); break;
-        default: hipLaunchKernelGGL(bp_dp_reduce_update<0>, dim3(grid), dim3(256), 0, d->comm, a); break;
-        }
-        if ((er = hipGetLastError()) != hipSuccess) return er;
+        if ((er = dp_reduce_layer(h, l)) != hipSuccess) return er;
     }
     return hipSuccess;
 }
@@ -1581,16 +1612,39 @@ static hipError_t dp_bunch(bp_handle *h, int first)
             CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
         }
         for (int l = L - 1; l >= 2; --l) CKE(launch_dgrad(h, h->stream, l, B));
-        // layer 1 (the largest segment, needed first by the next forward) goes out alone; the rest as ONE grouped launch:
-        // its exchange queues behind layer 1's on the comm stream anyway, and one launch + one event replace L-2 of each
         Prepared ws[BP_MAXLAYER]; int rest[BP_MAXLAYER], nrest = 0;
         const int one = 1;
-        CKE(launch_wgrad(h, h->stream, 1, B, x0, false));
-        CKE(dp_exchange_layers(h, &one, 1));
-        for (int l = 2; l < L; ++l) { ws[nrest] = prep_wgrad(h, l, B, h->y[l - 1], false); rest[nrest++] = l; }
-        if (nrest) {
-            CKE(run_wgrads(h->stream, ws, nrest, true));
-            CKE(dp_exchange_layers(h, rest, nrest));
+        const bool static_k = B == 128 || B == 256 || B == 512;         // (the LDS-DMA store kernel, the one that counts its tiles)
+        if (d->counters_ok && d->backend != BP_DP_TRANSPORT_RCCL && static_k && L - 1 <= 4) {
+            // ONE grouped weight-gradient launch, layer 1's tiles first; every tile counts itself into done[l] (bp_wgrad_dma.h), and
+            // the exchange stream -- queued right here, running beside the launch -- picks each layer up as soon as its count is
+            // complete: no event on this stream (each cost it a ~7 us bubble), no split of the launch, and layer 1's exchange
+            // overlaps the other layers' tiles instead of waiting behind a launch boundary.
+            int nw = 0;
+            for (int l = 1; l < L; ++l) {
+                ws[nw] = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], false);
+                ws[nw].e.done = d->done + l;
+                d->done_target[l] += (unsigned)(((h->ld[l - 1] + 63) / 64) * ((h->ld[l] + 63) / 64));
+                ++nw;
+            }
+            const DpPeers peers = dp_peers(d);
+            for (int l = 1; l < L; ++l) {
+                hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + l, d->done_target[l], peers, d->flags, d->world,
+                                   bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->epoch, d->budget_ticks, d->err, 1u);
+                CKE(hipGetLastError());
+                CKE(dp_reduce_layer(h, l));
+            }
+            CKE(run_wgrads(h->stream, ws, nw, true));
+        } else {
+            // layer 1 (the largest segment, needed first by the next forward) goes out alone; the rest as ONE grouped launch:
+            // its exchange queues behind layer 1's on the comm stream anyway, and one launch + one event replace L-2 of each
+            CKE(launch_wgrad(h, h->stream, 1, B, x0, false));
+            CKE(dp_exchange_layers(h, &one, 1));
+            for (int l = 2; l < L; ++l) { ws[nrest] = prep_wgrad(h, l, B, h->y[l - 1], false); rest[nrest++] = l; }
+            if (nrest) {
+                CKE(run_wgrads(h->stream, ws, nrest, true));
+                CKE(dp_exchange_layers(h, rest, nrest));
+            }
         }
     }
 #undef CKE

@@ -72,6 +72,7 @@ struct EpiArgs {
     int frame_off;                   // global frame index of row 0 of this bunch
     const uint8_t *mask; int ldmask; // injected dropout mask of the produced activation ([row][unit] bytes, 1 = drop;
                                      // bp_train_resident_masked, parity tests only) -- replaces the Philox draw
+    unsigned *done;                  // wgrad store (data parallel): +1 per finished tile, for the exchange stream (bp_dp.h); may be null
 };
 
 // ------------------------------------------------------------------ Philox4x32-10

@@ -134,6 +134,18 @@ struct WgradDma {
                 __syncthreads();
             }
             epilogue_block<EPI, 0, 16>(e, mb, nb, acc[0], lane, pre);
+            if constexpr (STORE) {
+                // data-parallel step: tell the exchange stream that this tile of the layer's gradient segment is complete, WITHOUT a
+                // kernel boundary (one grouped launch for all layers; the exchange of layer 1 starts while the other layers' tiles
+                // still run).  Every storing wave drains its stores, then one lane counts the tile.  No release fence: the gradient
+                // buffer is fine-grained memory, its consumers read it with system-scope loads, and bp_dp_attach's self-test
+                // checks exactly this hand-off on the group's devices before the step relies on it (bp_dp.h).
+                if (e.done) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_fetch_add(e.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
         }
     }
 };
