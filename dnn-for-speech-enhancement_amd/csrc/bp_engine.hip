@@ -80,7 +80,12 @@ struct bp_handle {
     int wcur;                                 // staging set of the resident window chunk
     bool windows;                             // the resident chunk is a window chunk
     struct { const float *fea, *tg, *nat; const int *ws, *tf, *nr; int D, win; } wv;   // views of set wcur
-    float *x0s, *tgs;                         // [Bp][ld_0], [Bp][ld_L]: the staged bunch
+    float *x0s, *tgs;                         // [Bp][ld_0], [Bp][ld_L]: the staged bunch (= tile stage_cur of the pair below)
+    float *x0s2[2], *tgs2[2]; int stage_cur;  // two staged tiles: while bunch i trains out of one, the output layer's reduce launch
+                                              // of bunch i stacks bunch i+1 into the other (bp_out_reduce_stage)
+    int next_first;                           // chunk frame of the bunch that follows the one being enqueued (-1: none / not a window chunk)
+    struct { bool valid; int first, tile; uint32_t step; unsigned gen; } pre;   // what the other tile holds
+    unsigned wgen;                            // bumped by every window upload (a pre-staged tile of the old chunk is void)
     hipStream_t copy_stream;
     hipEvent_t ev_copy;            // copy_stream: this chunk's H2D copies are done
     hipEvent_t ev_retired;         // main stream: the stacked buffer pair that is NOT current is no longer read
@@ -174,6 +179,8 @@ static int check_hyper(float, float, float, int, float, float, const char *);
 static hipError_t dp_bunch(bp_handle *h, int first);
 static int ensure_stacked(bp_handle *h);
 static hipError_t stage_bunch(bp_handle *h, int first, int rows, bool train);
+static StageArgs stage_args(bp_handle *h, int first, int rows, bool train, int tile, uint32_t step);
+static int stage_blocks(const bp_handle *h, const StageArgs &a);
 static hipError_t dp_flush(bp_handle *h);
 static int dp_gather_deltas(bp_handle *h);
 static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs);
@@ -217,6 +224,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->grouped = getenv("BP_NO_GROUPED") == nullptr;
     h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
     h->last_ms = 0.f; h->last_bunches = 0; h->dp = nullptr; h->params = h->deltas = nullptr;
+    h->next_first = -1; h->pre.valid = false; h->wgen = 0; h->stage_cur = 0;
 
 #define CK(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_err; bp_destroy(h); g_err = m; return _r; } } while (0)
 #define HK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(_e); bp_destroy(h); return fail(BP_ERR_DEVICE, m); } } while (0)
@@ -313,6 +321,7 @@ extern "C" int bp_set_hyper(bp_handle *h, float lrate, float momentum, float wei
         }
         h->cfg.dropoutflag = dropoutflag; h->cfg.visible_omit = visible_omit; h->cfg.hid_omit = hid_omit;
         h->th_vis = th_vis;
+        h->pre.valid = false;                                   // (a pre-staged bunch was masked with the old rate)
         h->th_hid = dropoutflag == 1 ? drop_threshold(hid_omit) : 0u;
         h->mask_lo = h->mask_hi = -1;
     }
@@ -376,10 +385,20 @@ static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const f
                            dim3(g.tiles_m * g.tiles_n, h->out_splits), dim3(256), 0, st, g, e);
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return er;
-        const int n4 = M * (cur / 4);
-        hipLaunchKernelGGL(bp_out_reduce, dim3((n4 + 255) / 256), dim3(256), 0, st, h->slabs, h->slab_stride,
-                           h->out_splits, M, cur, h->s[l], h->b[l], alpha, targ, e.scale, out,
-                           train ? h->dx[l] : (float *)nullptr);
+        const int n4 = M * (cur / 4), n_reduce = (n4 + 255) / 256;
+        OutReduceArgs ra; memset(&ra, 0, sizeof(ra));
+        ra.slabs = h->slabs; ra.slab_stride = h->slab_stride; ra.nsplit = h->out_splits; ra.M = M; ra.ld = cur; ra.n_true = h->s[l];
+        ra.bias = h->b[l]; ra.alpha = alpha; ra.targ = targ; ra.scale = e.scale; ra.out = out; ra.dedx = train ? h->dx[l] : (float *)nullptr;
+        if (train && h->windows && h->next_first >= 0 && st == h->stream) {
+            // a window chunk with another bunch behind this one: stack (and mask, with the NEXT step's Philox position) that bunch
+            // into the other tile from the spare workgroups of this launch
+            const int tile = 1 - h->stage_cur;
+            const StageArgs sa = stage_args(h, h->next_first, h->B, true, tile, h->step + 1);
+            hipLaunchKernelGGL(bp_out_reduce_stage, dim3((unsigned)(n_reduce + stage_blocks(h, sa))), dim3(256), 0, st, ra, n_reduce, sa);
+            h->pre.valid = true; h->pre.first = h->next_first; h->pre.tile = tile; h->pre.step = h->step + 1; h->pre.gen = h->wgen;
+            return hipGetLastError();
+        }
+        hipLaunchKernelGGL(bp_out_reduce, dim3((unsigned)n_reduce), dim3(256), 0, st, ra);
         return hipGetLastError();
     }
     e.C = train ? h->dx[l] : nullptr; e.ldc = cur;
@@ -814,15 +833,35 @@ static int ensure_stacked(bp_handle *h)
 
 // Stack rows [first, first+rows) of the resident window chunk into the bunch tile (x0s, and tgs when the chunk carries
 // targets); train: with the visible-layer dropout of this step.
-static hipError_t stage_bunch(bp_handle *h, int first, int rows, bool train)
+static StageArgs stage_args(bp_handle *h, int first, int rows, bool train, int tile, uint32_t step)
 {
     const int L = h->L, ld0 = h->ld[0], ldL = h->ld[L - 1];
-    const int yb_in = (ld0 + 255) / 256, yb_t = h->wv.tg ? (ldL + 255) / 256 : 0;
-    hipLaunchKernelGGL(bp_stage_bunch, dim3((unsigned)((rows + 3) / 4), (unsigned)(yb_in + yb_t)), dim3(256), 0, h->stream,
-                       h->x0s, ld0, h->s[0], h->wv.fea, h->wv.D, h->wv.win, h->wv.nat, h->wv.ws + first,
-                       h->wv.nr ? h->wv.nr + first : (const int *)nullptr, rows, train ? h->th_vis : 0u, h->cfg.rank_frame_offset,
-                       (uint32_t)h->cfg.seed, (uint32_t)(h->cfg.seed >> 32), h->step, h->wv.tg ? h->tgs : (float *)nullptr, ldL,
-                       h->s[L - 1], h->wv.tg, h->wv.tf ? h->wv.tf + first : (const int *)nullptr, yb_in);
+    StageArgs a; memset(&a, 0, sizeof(a));
+    a.x = h->x0s2[tile]; a.ld = ld0; a.width = h->s[0];
+    a.fea = h->wv.fea; a.fea_dim = h->wv.D; a.win = h->wv.win; a.nat = h->wv.nat;
+    a.win_start = h->wv.ws + first; a.nat_row = h->wv.nr ? h->wv.nr + first : (const int *)nullptr;
+    a.rows = rows; a.thresh = train ? h->th_vis : 0u; a.frame_off = h->cfg.rank_frame_offset;
+    a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32); a.step = step;
+    a.t = h->wv.tg ? h->tgs2[tile] : (float *)nullptr; a.ldt = ldL; a.twidth = h->s[L - 1];
+    a.targ_frames = h->wv.tg; a.targ_frame = h->wv.tf ? h->wv.tf + first : (const int *)nullptr;
+    a.yb_in = (ld0 + 255) / 256; a.nbx = (rows + 3) / 4;
+    return a;
+}
+static int stage_blocks(const bp_handle *h, const StageArgs &a) { return a.nbx * (a.yb_in + (a.t ? (h->ld[h->L - 1] + 255) / 256 : 0)); }
+
+static hipError_t stage_bunch(bp_handle *h, int first, int rows, bool train)
+{
+    // the bunch may already sit in the other tile: stacked by the previous bunch's output-layer reduce launch (same chunk, same
+    // dropout stream position)
+    if (train && h->pre.valid && h->pre.first == first && h->pre.step == h->step && h->pre.gen == h->wgen && rows == h->B) {
+        h->stage_cur = h->pre.tile; h->pre.valid = false;
+        h->x0s = h->x0s2[h->stage_cur]; h->tgs = h->tgs2[h->stage_cur];
+        return hipSuccess;
+    }
+    h->pre.valid = false;
+    h->x0s = h->x0s2[h->stage_cur]; h->tgs = h->tgs2[h->stage_cur];
+    const StageArgs a = stage_args(h, first, rows, train, h->stage_cur, h->step);
+    hipLaunchKernelGGL(bp_stage_bunch, dim3((unsigned)stage_blocks(h, a)), dim3(256), 0, h->stream, a);
     return hipGetLastError();
 }
 
@@ -850,8 +889,10 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
     HIPCHK(hipSetDevice(h->cfg.device));
     if (!h->x0s) {
         int r;
-        if ((r = dev_alloc(h, &h->x0s, (size_t)h->Bp * h->ld[0])) != BP_OK || (r = dev_alloc(h, &h->tgs, (size_t)h->Bp * h->ld[L - 1])) != BP_OK)
-            return r;
+        for (int k = 0; k < 2; ++k)
+            if ((r = dev_alloc(h, &h->x0s2[k], (size_t)h->Bp * h->ld[0])) != BP_OK || (r = dev_alloc(h, &h->tgs2[k], (size_t)h->Bp * h->ld[L - 1])) != BP_OK)
+                return r;
+        h->stage_cur = 0; h->x0s = h->x0s2[0]; h->tgs = h->tgs2[0];
         HIPCHK(hipStreamSynchronize(h->stream));                // (dev_alloc zero-fills on the main stream)
     }
     if (n > 0) {
@@ -890,6 +931,7 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
         h->wv.D = D; h->wv.win = ctx * D;
     }
     h->windows = true;
+    h->wgen++; h->pre.valid = false;
     h->chunk_frames = n;
     h->mask_lo = h->mask_hi = -1;
     return BP_OK;
@@ -938,10 +980,12 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     if (nb > 0 && use_mask(h)) HIPCHK(mask_range(h, first_frame, nb * h->B));
     for (int i = 0; i < nb; ++i) {
+        h->next_first = (h->windows && !h->bf && i + 1 < nb) ? first_frame + (i + 1) * h->B : -1;
         if (h->dp) HIPCHK(dp_bunch(h, first_frame + i * h->B));
         else HIPCHK(bunch(h, first_frame + i * h->B, true));
         h->step++;
     }
+    h->next_first = -1;
     if (h->dp && nb > 0) HIPCHK(dp_flush(h));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_bunches = nb;

@@ -912,39 +912,48 @@ __global__ __launch_bounds__(256, K::MIN_WG) void bp_gemm_multi(const MultiArgs 
 // materialised: what stays resident are the raw frames (11x fewer bytes) and this one L2-sized tile per bunch.
 // One thread = one column x 4 consecutive rows (= one Philox block; coalesced 4-byte accesses: raw rows of 257 floats
 // are not 16-byte aligned); blockIdx.y < yb_in sweeps the input columns, the rest the target columns.
-__global__ void bp_stage_bunch(float *__restrict__ x, int ld, int width, const float *__restrict__ fea, int fea_dim, int win,
-                               const float *__restrict__ nat, const int *__restrict__ win_start, const int *__restrict__ nat_row,
-                               int rows, uint32_t thresh, int frame_off, uint32_t seed_lo, uint32_t seed_hi, uint32_t step,
-                               float *__restrict__ t, int ldt, int twidth, const float *__restrict__ targ_frames,
-                               const int *__restrict__ targ_frame, int yb_in)
+struct StageArgs {
+    float *x; int ld, width;                      // staged input tile [rows][ld], unpadded width
+    const float *fea; int fea_dim, win;           // raw frames [n_frames][fea_dim]; win = context * fea_dim floats per window
+    const float *nat; const int *win_start, *nat_row;   // noise-aware rows; per-sample tables (already offset to the bunch's first sample)
+    int rows; uint32_t thresh; int frame_off; uint32_t seed_lo, seed_hi, step;
+    float *t; int ldt, twidth; const float *targ_frames; const int *targ_frame;   // staged targets (t may be null)
+    int yb_in;                                    // column blocks of the input part; blocks by >= yb_in sweep the target columns
+    int nbx;                                      // row blocks (rows / 4, rounded up): block (bx, by) of the flat index e is bx = e % nbx, by = e / nbx
+};
+__device__ __forceinline__ void stage_block(const StageArgs &a, int bx, int by, int tx)
 {
-    const int r0 = blockIdx.x * 4;
+    const int r0 = bx * 4;
     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if ((int)blockIdx.y >= yb_in) {
-        const int c = ((int)blockIdx.y - yb_in) * blockDim.x + threadIdx.x;
-        if (c >= ldt) return;
-        if (c < twidth) {
+    if (by >= a.yb_in) {
+        const int c = (by - a.yb_in) * 256 + tx;
+        if (c >= a.ldt) return;
+        if (c < a.twidth) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = targ_frames[(size_t)targ_frame[r0 + j] * twidth + c];
+            for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) v[j] = a.targ_frames[(size_t)a.targ_frame[r0 + j] * a.twidth + c];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (r0 + j < rows) t[(size_t)(r0 + j) * ldt + c] = v[j];
+        for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) a.t[(size_t)(r0 + j) * a.ldt + c] = v[j];
         return;
     }
-    const int c = blockIdx.y * blockDim.x + threadIdx.x;
-    if (c >= ld) return;
+    const int c = by * 256 + tx;
+    if (c >= a.ld) return;
     // all four rows' loads first (independent), the Philox block meanwhile, then the four stores
-    if (c < win) {
+    if (c < a.win) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = fea[(size_t)win_start[r0 + j] * fea_dim + c];
-    } else if (c < width) {
+        for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) v[j] = a.fea[(size_t)a.win_start[r0 + j] * a.fea_dim + c];
+    } else if (c < a.width) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = nat[(size_t)nat_row[r0 + j] * fea_dim + (c - win)];
+        for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) v[j] = a.nat[(size_t)a.nat_row[r0 + j] * a.fea_dim + (c - a.win)];
     }
     uint32_t w[4] = {~0u, ~0u, ~0u, ~0u};
-    if (thresh && c < width) drop_words4(w, r0, c, frame_off, (uint32_t)width, 0u, step, seed_lo, seed_hi);
+    if (a.thresh && c < a.width) drop_words4(w, r0, c, a.frame_off, (uint32_t)a.width, 0u, a.step, a.seed_lo, a.seed_hi);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (r0 + j < rows) x[(size_t)(r0 + j) * ld + c] = w[j] < thresh ? 0.0f : v[j];
+    for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) a.x[(size_t)(r0 + j) * a.ld + c] = w[j] < a.thresh ? 0.0f : v[j];
+}
+__global__ __launch_bounds__(256) void bp_stage_bunch(const StageArgs a)
+{
+    stage_block(a, blockIdx.x % a.nbx, blockIdx.x / a.nbx, threadIdx.x);
 }
 
 // Visible-layer dropout of the resident chunk (BP_GPU.cu:536-539 masks the device copy of the
@@ -1012,32 +1021,47 @@ __global__ void bp_fill_normal(float *buf, int ld, int width, int rows, uint32_t
 
 // Second half of a split-K output layer: out = sum_z slab[z] + bias; dEdX = scale*(out - targ)
 // (kernSubClean, DevFunc.cu:253-268).  One thread = 4 consecutive columns of one frame.
-__global__ void bp_out_reduce(const float *slabs, size_t slab_stride, int nsplit, int M, int ld, int n_true,
-                              const float *bias, float alpha, const float *targ, float scale, float *out, float *dedx)
+struct OutReduceArgs {
+    const float *slabs; size_t slab_stride; int nsplit, M, ld, n_true;
+    const float *bias; float alpha; const float *targ; float scale; float *out, *dedx;
+};
+__device__ __forceinline__ void out_reduce_block(const OutReduceArgs &a, int block, int tx)
 {
-    const int c4 = blockIdx.x * blockDim.x + threadIdx.x, per_row = ld / 4;
-    if (c4 >= M * per_row) return;
+    const int c4 = block * 256 + tx, per_row = a.ld / 4;
+    if (c4 >= a.M * per_row) return;
     const int m = c4 / per_row, n = (c4 % per_row) * 4;
-    const size_t i = (size_t)m * ld + n;
-    float4 s = *reinterpret_cast<const float4 *>(slabs + i);
-    for (int z = 1; z < nsplit; ++z) {
-        const float4 p = *reinterpret_cast<const float4 *>(slabs + z * slab_stride + i);
+    const size_t i = (size_t)m * a.ld + n;
+    float4 s = *reinterpret_cast<const float4 *>(a.slabs + i);
+    for (int z = 1; z < a.nsplit; ++z) {
+        const float4 p = *reinterpret_cast<const float4 *>(a.slabs + z * a.slab_stride + i);
         s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
     }
-    const float4 b = *reinterpret_cast<const float4 *>(bias + n);
-    float o[4] = {alpha * s.x + b.x, alpha * s.y + b.y, alpha * s.z + b.z, alpha * s.w + b.w};
+    const float4 b = *reinterpret_cast<const float4 *>(a.bias + n);
+    float o[4] = {a.alpha * s.x + b.x, a.alpha * s.y + b.y, a.alpha * s.z + b.z, a.alpha * s.w + b.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) if (n + j >= n_true) o[j] = 0.0f;
-    if (out) *reinterpret_cast<float4 *>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
-    if (dedx) {
-        const float4 t = *reinterpret_cast<const float4 *>(targ + i);
-        float4 d = make_float4(scale * (o[0] - t.x), scale * (o[1] - t.y), scale * (o[2] - t.z), scale * (o[3] - t.w));
-        if (n + 0 >= n_true) d.x = 0.f;
-        if (n + 1 >= n_true) d.y = 0.f;
-        if (n + 2 >= n_true) d.z = 0.f;
-        if (n + 3 >= n_true) d.w = 0.f;
-        *reinterpret_cast<float4 *>(dedx + i) = d;
+    for (int j = 0; j < 4; ++j) if (n + j >= a.n_true) o[j] = 0.0f;
+    if (a.out) *reinterpret_cast<float4 *>(a.out + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (a.dedx) {
+        const float4 t = *reinterpret_cast<const float4 *>(a.targ + i);
+        float4 d = make_float4(a.scale * (o[0] - t.x), a.scale * (o[1] - t.y), a.scale * (o[2] - t.z), a.scale * (o[3] - t.w));
+        if (n + 0 >= a.n_true) d.x = 0.f;
+        if (n + 1 >= a.n_true) d.y = 0.f;
+        if (n + 2 >= a.n_true) d.z = 0.f;
+        if (n + 3 >= a.n_true) d.w = 0.f;
+        *reinterpret_cast<float4 *>(a.dedx + i) = d;
     }
+}
+__global__ __launch_bounds__(256) void bp_out_reduce(const OutReduceArgs a)
+{
+    out_reduce_block(a, blockIdx.x, threadIdx.x);
+}
+// The reduce AND, in the same launch, the stacking of the NEXT bunch of a window chunk into the other staged tile
+// (workgroups >= n_reduce): the reduce is 80 workgroups of launch latency on a chip that is otherwise idle at that point of
+// the step, so the next bunch's bp_stage_bunch (5.1 us as its own launch in front of every bunch, round 3) rides along for free.
+__global__ __launch_bounds__(256) void bp_out_reduce_stage(const OutReduceArgs a, int n_reduce, const StageArgs st)
+{
+    if ((int)blockIdx.x < n_reduce) out_reduce_block(a, blockIdx.x, threadIdx.x);
+    else { const int e = blockIdx.x - n_reduce; stage_block(st, e % st.nbx, e / st.nbx, threadIdx.x); }
 }
 
 // Momentum update on a flat [W|b] gradient segment after the data-parallel sum

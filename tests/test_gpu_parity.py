@@ -380,6 +380,36 @@ def test_window_chunk_equals_stacked_chunk(pkg, nat, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nat", [False, True])
+def test_window_bunches_prestaged_by_the_output_layer_launch(pkg, nat):
+    """With a split-K output layer (hidden width >= 1024) the reduce launch of bunch i also stacks + masks bunch i+1 into the
+    second staged tile (bp_out_reduce_stage; Philox position of step i+1), so only the first bunch of a call is stacked by a
+    launch of its own.  Same weights, bit for bit, as the chunk handed over stacked by the host; chunks of 6 and 1 bunches,
+    a second train call that starts in the middle of the resident chunk, CV at the end."""
+    rs = np.random.default_rng(35)
+    D, ctx, od, B = 21, 5, 17, 32
+    ls = [D * ctx + (D if nat else 0), 1024, od]
+    W = [None] + [(rs.normal(size=(ls[l - 1], ls[l])) * 0.05).astype(np.float32) for l in (1, 2)]
+    b = [None] + [(rs.normal(size=ls[l]) * 0.1).astype(np.float32) for l in (1, 2)]
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=11)
+    g1 = pkg.BP_GPU(1, 3, ls, B, 0.2, 0.5, 1e-4, W, b, max_chunk_frames=256, **kw)
+    g2 = pkg.BP_GPU(1, 3, ls, B, 0.2, 0.5, 1e-4, W, b, max_chunk_frames=256, **kw)
+    for n in (200, 40, 200):
+        fea, tg, ws, tf, natm, nr, rows, trows = _window_case(rs, nat, D=D, ctx=ctx, od=od, n=n)
+        g1.train(n, rows, trows)
+        g2.train_windows(fea, tg, ctx, ws, tf, natm, nr)
+        if n >= 5 * B:                                           # a second call on the resident chunk, starting in its middle
+            g1.train_resident(B, 3 * B); g2.train_resident(B, 3 * B)
+    assert g1.CrossValid(n, rows, trows) == g2.CrossValid_windows(fea, tg, ctx, ws, tf, natm, nr)
+    for g in (g1, g2):
+        g.W_, g.b_ = [None] + [np.zeros_like(W[l]) for l in (1, 2)], [None] + [np.zeros_like(b[l]) for l in (1, 2)]
+        g.returnWeights(g.W_, g.b_)
+    for l in (1, 2):
+        assert np.array_equal(g1.W_[l], g2.W_[l]) and np.array_equal(g1.b_[l], g2.b_[l])
+    g1.close(); g2.close()
+
+
+@pytest.mark.gpu
 def test_window_and_stacked_chunks_interleave_at_benchmark_geometry(pkg):
     """The geometry of BASELINE.json's C2 input (11 frames x 257 bins = 2827, rows of 257 floats are not 16-byte aligned,
     256-frame bunches) on one handle that is fed window chunks and stacked chunks in turn, several uploads queued back to
