@@ -4,15 +4,19 @@
 // bf16 (round-to-nearest-even) is the storage type of everything a GEMM reads: activations y_l, back-propagated
 // errors dEdX_l and a shadow copy of the weights that the update epilogue refreshes.
 //
-// Layout idea: every GEMM of the step becomes  C[m][n] = sum_k A[m][k] * B[n][k]  with BOTH operands k-contiguous,
-// because each bf16 array is kept in two orientations, written together by the producing epilogue (a lane owns one
-// column and 4-row groups of a 32x32 MFMA block, so the transposed copy is written as 8-byte runs):
-//     fwd   l : y_l[f][c]      = act( y_{l-1}[f][p] . WbT_l[c][p] )          y  : [frames][units]   yT : [units][frames]
+// Layout idea: every GEMM of the step is  C[m][n] = sum_k A[m][k] * B[n][k].  Activations and back-propagated errors are
+// kept in two orientations, written together by the producing epilogue (a lane owns one column and 4-row groups of a 32x32
+// MFMA block, so the transposed copy is written as 8-byte runs), which makes their operands k-contiguous everywhere:
+//     fwd   l : y_l[f][c]      = act( y_{l-1}[f][p] . Wb_l[p][c] )           y  : [frames][units]   yT : [units][frames]
 //     dgrad l : dx_{l-1}[f][p] = act'(y_{l-1}) * ( dx_l[f][c] . Wb_l[p][c] ) dx : [frames][units]   dxT: [units][frames]
-//     wgrad l : G_l[p][c]      = yT_{l-1}[p][f] . dxT_l[c][f]                Wb : [prev][cur]       WbT: [cur][prev]
-// so one kernel (64x64x64 tiles, 4 waves, ds_read_b128 fragment reads from padded k-contiguous LDS rows) serves all
-// three with different epilogues.  This path is a parity configuration, not the benchmarked one: it is written for
-// clarity, not tuned to the bf16 MFMA peak (a 32x32 block per wave is LDS-read bound at ~half of it).
+//     wgrad l : G_l[p][c]      = yT_{l-1}[p][f] . dxT_l[c][f]                Wb : [prev][cur]  (ONE shadow of the weights)
+// The weights have ONE bf16 shadow, in the reference's own layout [prev][cur].  For dgrad that is k-contiguous (k = cur).
+// For the forward k = prev runs down the rows: its B tile goes into LDS as it lies in memory ([k][n], full 128-byte
+// lines) and the MFMA fragments -- 8 consecutive k of one column per lane -- come out of it through the hardware
+// transpose read ds_read_b64_tr_b16 (two per fragment).  Round 3 kept a second, transposed shadow instead, which the
+// HBM-bound weight-gradient launch had to write: 2 bytes per parameter and step (160 MB at configs[4]).
+// One kernel (128/64/32 x 64 x 64 tiles, 4 waves, ds_read_b128 fragment reads from padded LDS rows) serves all three
+// GEMMs with different epilogues.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,12 +60,20 @@ static constexpr int BF_NPF = 3;                                     // k-tiles 
 // BM = 128: 256 threads, waves 2 x 2, each wave TWO 32x32 blocks along m (64 x 32): a third less operand traffic per
 // FLOP than 64 x 64 and every B fragment feeds two MFMAs -- used when 128-row tiles still give every CU a workgroup
 // (the 4096-wide layers of configs[4]: these GEMMs are bound by operand delivery into the CUs, not by the bf16 MFMA rate).
-template <int EPI, int BM>
+// BKN: the B operand lies [k][n] in memory (n contiguous; the forward's weights Wb[prev][cur]) instead of [n][k]: its
+// tile is staged as 64 k-rows of 64 n (BF_LDB halfs apart: 192 bytes, so that the 4 k-rows x 64 bytes a half-wave's
+// transpose read touches fall into the four quarters of the 256-byte bank row) and read with ds_read_b64_tr_b16.
+static constexpr int BF_LDB = 96;
+typedef short bf_v4s __attribute__((ext_vector_type(4)));
+typedef short bf_v8s __attribute__((ext_vector_type(8)));
+template <int EPI, int BM, bool BKN = false>
 __global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
 {
     constexpr int NTHR = BM == 32 ? 128 : 256, ROWS = BM + BF_BN, NCHK = ROWS * 8 / NTHR;     // 16-byte chunks per thread and tile
     constexpr int TMB = BM == 128 ? 2 : 1;                                                      // 32x32 blocks per wave along m
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * ROWS * BF_LDS];
+    constexpr int NCHK_A = BM * 8 / NTHR;                                                       // chunks i < NCHK_A belong to A, the rest to B
+    constexpr int STAGE_H = BKN ? BM * BF_LDS + BF_BK * BF_LDB : ROWS * BF_LDS;                 // halfs per LDS stage
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_H];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = (BM >= 64) ? wave >> 1 : 0, wn = wave & 1;
     // XCD-aware tile map (block b runs on XCD b % 8): the workgroups that share a B panel (same tile_n, all tile_m)
     // sit on one XCD, so the panel is fetched into that XCD's L2 once instead of eight times
@@ -78,9 +90,15 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const Bf
 #pragma unroll
     for (int i = 0; i < NCHK; ++i) {
         const int c = tid + i * NTHR, row = c >> 3, kc = (c & 7) * 8;
-        src[i] = row < BM ? g.A + (size_t)(m0 + row) * g.lda + kc : g.B + (size_t)(n0 + row - BM) * g.ldb + kc;
-        dst[i] = row * BF_LDS + kc;
+        if (BKN && i >= NCHK_A) {                            // B tile [k][n]: row = k-row of the tile, 8 consecutive n per chunk
+            src[i] = g.B + (size_t)(row - BM) * g.ldb + n0 + kc;
+            dst[i] = BM * BF_LDS + (row - BM) * BF_LDB + kc;
+        } else {
+            src[i] = row < BM ? g.A + (size_t)(m0 + row) * g.lda + kc : g.B + (size_t)(n0 + row - BM) * g.ldb + kc;
+            dst[i] = row * BF_LDS + kc;
+        }
     }
+    const size_t bstep = BKN ? (size_t)g.ldb : 1;            // halfs per k of the B operand's source
     // ---- epilogue mapping: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block
     const int n = n0 + wn * 32 + (lane & 31);
     const int rbase = m0 + wm * 32 * TMB + 4 * (lane >> 5);   // (wm = 0 for BM = 32); block i of the wave: + 32*i
@@ -121,21 +139,32 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const Bf
 #define BF_LOAD(R, t)                                                                                   \
     do {                                                                                                \
         const int kk_ = ((t) < nt ? (t) : nt - 1) * BF_BK;      /* unconditional, clamped */             \
-        _Pragma("unroll") for (int i = 0; i < NCHK; ++i) R.v[i] = *reinterpret_cast<const uint4 *>(src[i] + kk_); \
+        _Pragma("unroll") for (int i = 0; i < NCHK; ++i)                                                \
+            R.v[i] = *reinterpret_cast<const uint4 *>(src[i] + ((BKN && i >= NCHK_A) ? (size_t)kk_ * bstep : (size_t)kk_)); \
     } while (0)
 #define BF_STORE(R, st)                                                                                 \
     do {                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NCHK; ++i) { const uint4 v_ = R.v[i];                     \
-            *reinterpret_cast<uint4 *>(smem + (st) * ROWS * BF_LDS + dst[i]) = v_; }                    \
+            *reinterpret_cast<uint4 *>(smem + (st) * STAGE_H + dst[i]) = v_; }                          \
     } while (0)
     const int arow = wm * 32 * TMB + (lane & 31), brow = BM + wn * 32 + (lane & 31), kh = (lane >> 5) * 8;
+    // BKN: this lane's piece of the transpose read (16 lanes fetch 4 k-rows x 16 n: lane i supplies row i>>2, 4 n at 4*(i&3),
+    // and receives column i of that 4x16 block = 4 consecutive k of n = 16*((lane>>4)&1) + i; lanes 32..63 take k + 8)
+    const int tr_off = (8 * (lane >> 5) + ((lane & 15) >> 2)) * BF_LDB + wn * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 // multiply tile t (LDS stage t&1); RN holds tile t+1: move it to the other stage and refill RN with tile t+1+NPF
 #define BF_ITER(t, RN)                                                                                  \
     do {                                                                                                \
-        const bf16_t *base_ = smem + ((t) & 1) * ROWS * BF_LDS;                                         \
+        const bf16_t *base_ = smem + ((t) & 1) * STAGE_H;                                               \
         const bf16_t *ap_ = base_ + arow * BF_LDS + kh, *bp_ = base_ + brow * BF_LDS + kh;              \
         bf16x8_t a_[TMB][4], b_[4];                                                                     \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                              \
+            if constexpr (BKN) {                                                                        \
+                typedef __attribute__((address_space(3))) bf_v4s *lds4_;                                \
+                const bf16_t *tp_ = base_ + BM * BF_LDS + tr_off + 16 * q_ * BF_LDB;                    \
+                const bf_v4s lo_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_)(tp_));               \
+                const bf_v4s hi_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_)(tp_ + 4 * BF_LDB));  \
+                b_[q_] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7)); \
+            } else                                                                                      \
             b_[q_] = *reinterpret_cast<const bf16x8_t *>(bp_ + 16 * q_);                                \
             _Pragma("unroll") for (int i_ = 0; i_ < TMB; ++i_) a_[i_][q_] = *reinterpret_cast<const bf16x8_t *>(ap_ + i_ * 32 * BF_LDS + 16 * q_); \
         }                                                                                               \
@@ -221,7 +250,7 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const Bf
         for (int j = 0; j < 4; ++j)
             if (mq + j < e.m_limit) e.C[(size_t)(mq + j) * e.ldc + n] = hb[j];
         const uint2 pk = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
-        *reinterpret_cast<uint2 *>(e.CT + (size_t)n * e.ldct + mq) = pk;
+        if (e.CT) *reinterpret_cast<uint2 *>(e.CT + (size_t)n * e.ldct + mq) = pk;     // (the weights keep ONE shadow: no transposed copy)
     }
     }
 }
@@ -240,6 +269,7 @@ __global__ void bp_to_bf16_both(const float *src, int lds, int rows, int cols, b
         if (r < rows_pad && c < cols_pad) out[(size_t)r * ldo + c] = h;
         tile[j][threadIdx.x] = h;
     }
+    if (!outT) return;                               // (uniform: the weights' single shadow)
     __syncthreads();
     const int rt = r0 + threadIdx.x;                 // transposed: thread x walks rows of the source
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {

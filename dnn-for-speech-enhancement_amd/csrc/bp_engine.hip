@@ -95,7 +95,7 @@ struct bp_handle {
     // compute_dtype == 1 (bp_bf16.h): bf16 copies, each in both orientations
     bool bf;
     int Bp;                                                  // bunch rows rounded up to 64
-    bf16_t *Wb[BP_MAXLAYER], *WbT[BP_MAXLAYER];              // [prev][cur], [cur][prev]
+    bf16_t *Wb[BP_MAXLAYER];                                 // ONE bf16 shadow of the weights, [prev][cur] (the forward reads it through the LDS transpose read)
     bf16_t *yb[BP_MAXLAYER], *ybT[BP_MAXLAYER];              // [Bp][ld_l], [ld_l][Bp]   (l = 0: the input bunch)
     bf16_t *dxb[BP_MAXLAYER], *dxbT[BP_MAXLAYER];
 };
@@ -281,7 +281,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
             if (l >= 1) {
                 CK(bf_alloc(h, &h->dxb[l], act)); CK(bf_alloc(h, &h->dxbT[l], act));
                 const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
-                CK(bf_alloc(h, &h->Wb[l], nw)); CK(bf_alloc(h, &h->WbT[l], nw));
+                CK(bf_alloc(h, &h->Wb[l], nw));
                 HK(bf_shadow(h, l));
             }
         }
@@ -565,23 +565,23 @@ static hipError_t bf_convert(bp_handle *h, const float *src, int lds, int rows, 
 static hipError_t bf_shadow(bp_handle *h, int l)
 {
     const int prev = h->ld[l - 1], cur = h->ld[l];
-    return bf_convert(h, h->W[l], cur, prev, cur, h->Wb[l], cur, h->WbT[l], prev, prev, cur);
+    return bf_convert(h, h->W[l], cur, prev, cur, h->Wb[l], cur, nullptr, 0, prev, cur);
 }
 // BM = 32 tiles (128-thread workgroups) when 64-row tiles would leave CUs without work
-template <int EPI>
+template <int EPI, bool BKN = false>
 static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int M, int N)
 {
     g.tiles_n = N / 64;
     static const bool no128 = getenv("BP_BF16_NO128") != nullptr;                 // development A/B switch
     if (!no128 && M % 128 == 0 && (M / 128) * g.tiles_n >= 256) {                 // 128-row tiles still fill the chip
         g.tiles_m = M / 128;
-        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
+        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128, BKN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
     } else if ((M / 64) * g.tiles_n >= 512) {
         g.tiles_m = M / 64;
-        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 64>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
+        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 64, BKN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
     } else {
         g.tiles_m = M / 32;
-        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 32>), dim3(g.tiles_m * g.tiles_n), dim3(128), 0, h->stream, g, e);
+        hipLaunchKernelGGL((bp_gemm_bf16<EPI, 32, BKN>), dim3(g.tiles_m * g.tiles_n), dim3(128), 0, h->stream, g, e);
     }
     return hipGetLastError();
 }
@@ -591,7 +591,7 @@ static hipError_t bf_fwd(bp_handle *h, int l, int M, const float *targ, float *o
 {
     const int L = h->L, prev = h->ld[l - 1], cur = h->ld[l];
     BfGemmArgs g; memset(&g, 0, sizeof(g));
-    g.A = h->yb[l - 1]; g.lda = prev; g.B = h->WbT[l]; g.ldb = prev; g.K = prev;
+    g.A = h->yb[l - 1]; g.lda = prev; g.B = h->Wb[l]; g.ldb = cur; g.K = prev;       // B = Wb [k = prev][n = cur]: the BKN form of the kernel
     BfEpiArgs e; memset(&e, 0, sizeof(e));
     e.m_limit = M; e.n_limit = cur; e.n_true = h->s[l]; e.bias = h->b[l]; e.alpha = alpha; e.act = h->cfg.activation;
     e.ldc = cur; e.ldct = h->Bp;
@@ -600,12 +600,12 @@ static hipError_t bf_fwd(bp_handle *h, int l, int M, const float *targ, float *o
         e.drop_thresh = train ? h->th_hid : 0u;
         e.seed_lo = (uint32_t)h->cfg.seed; e.seed_hi = (uint32_t)(h->cfg.seed >> 32);
         e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
-        return bf_launch<BEPI_FWD_HIDDEN>(h, g, e, h->Bp, cur);
+        return bf_launch<BEPI_FWD_HIDDEN, true>(h, g, e, h->Bp, cur);
     }
     e.scale = 2.0f / (float)h->Bg;
     e.targ = targ; e.ldt = cur; e.out = out; e.ldo = cur;
     if (train) { e.C = h->dxb[l]; e.CT = h->dxbT[l]; }
-    return bf_launch<BEPI_FWD_OUT>(h, g, e, h->Bp, cur);
+    return bf_launch<BEPI_FWD_OUT, true>(h, g, e, h->Bp, cur);
 }
 static hipError_t bf_input(bp_handle *h, const float *x0, int M)
 {
@@ -635,7 +635,7 @@ static hipError_t bf_wgrad(bp_handle *h, int l, bool fused)
     const float c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr;
     if (fused) {
         e.W = h->W[l]; e.D = h->dW[l]; e.mom = m; e.c1 = c1; e.wc = h->cfg.weightcost; e.ndiv = (float)h->Bg;
-        e.C = h->Wb[l]; e.ldc = cur; e.CT = h->WbT[l]; e.ldct = prev;
+        e.C = h->Wb[l]; e.ldc = cur; e.CT = nullptr; e.ldct = 0;
         er = bf_launch<BEPI_WGRAD_UPDATE>(h, g, e, prev, cur);
     } else {
         e.W = h->grad + h->g_off[l];
@@ -673,7 +673,7 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
                 p.e.C = h->W[l]; p.e.aux2 = h->dW[l]; p.e.ldaux2 = cur;
                 p.e.mom = m; p.e.c1 = c1; p.e.wc = h->cfg.weightcost; p.e.ndiv = (float)h->Bg;
                 p.e.bias_w = h->b[l]; p.e.bias_d = h->db[l];
-                p.Wb = h->Wb[l]; p.ldwb = cur; p.WbT = h->WbT[l]; p.ldwbt = prev;
+                p.Wb = h->Wb[l]; p.ldwb = cur;
             } else {
                 p.e.C = h->grad + h->g_off[l];
                 p.e.bias_g = h->grad + h->g_off[l] + (size_t)prev * cur;

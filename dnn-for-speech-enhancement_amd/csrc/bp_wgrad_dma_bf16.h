@@ -3,7 +3,7 @@
 //
 //   G_l = Y_{l-1}^T . dEdX_l   (SgemmNT, DevFunc.h:57-67; BP_GPU.cu:642) with bf16 operands and fp32 accumulation
 //   (v_mfma_f32_32x32x16_bf16), then kernUpdatedelta + kernAccSum (DevFunc.cu:313-318, 270-277) on the fp32 master
-//   W / delta while the tile is in registers, the refreshed bf16 copies of W in both orientations, and the bias
+//   W / delta while the tile is in registers, the refreshed bf16 shadow of W, and the bias
 //   gradient (kernAccSumrow, DevFunc.cu:224-242) by m-tile 0 from the dEdX panel it streams anyway.
 //
 // This is the structure of bp_wgrad_dma.h carried over to the bf16 operands.  Both operands are the TRANSPOSED
@@ -14,8 +14,8 @@
 // chunk per lane, 32 rows per half-wave) then touches all 64 banks once per 16-lane group.  64x64 tiles, 4 waves of
 // one 32x32 block, 32-frame k-tiles in a 4-stage ring (32 KB => 4 workgroups per CU), three tiles in flight, ONE raw
 // s_barrier per k-tile with an exact counted vmcnt; the W / delta tile is fetched by plain loads issued right behind
-// the LAST operand tile.  The step is HBM-bound here (20 bytes per parameter: fp32 W and delta read + written, two bf16
-// shadows written); what this kernel buys over bp_gemm_bf16<BEPI_WGRAD_UPDATE> is occupancy (80 VGPRs), no register
+// the LAST operand tile.  The step is HBM-bound here (20 bytes per parameter: fp32 W and delta read + written, one bf16
+// shadow written); what this kernel buys over bp_gemm_bf16<BEPI_WGRAD_UPDATE> is occupancy (80 VGPRs), no register
 // staging, one launch for all layers instead of one GEMM + one bias kernel per layer.
 #pragma once
 #include "bp_kernels.h"
@@ -27,7 +27,7 @@ struct BfWgradProblem {
     int ldk;                           // halfs per operand row (bunch rows rounded up to 64)
     int tiles_m, tiles_n;
     EpiArgs e;                         // fp32 side exactly as bp_wgrad_dma: C = W (or G), aux2 = delta, bias_w/d/g, mom, c1, wc, ndiv
-    bf16_t *Wb, *WbT; int ldwb, ldwbt; // refreshed shadow copies [prev][cur] / [cur][prev] (fused update only)
+    bf16_t *Wb; int ldwb;              // refreshed bf16 shadow [prev][cur] (fused update only)
 };
 enum { BF_WGRAD_MAXP = 8 };
 struct BfWgradMulti { BfWgradProblem p[BF_WGRAD_MAXP]; int first_tile[BF_WGRAD_MAXP + 1]; int n; };
@@ -132,12 +132,13 @@ struct WgradDmaBf {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) e.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n] = acc[r];
             } else {
-                // The two bf16 shadows leave through LDS so that they reach memory as FULL 128-byte lines: written straight
-                // from the accumulator layout they are 64-byte (Wb) and 16-byte (WbT) pieces of lines, and cost 112 us of an
-                // 813 us configs[4] step for 14 % of its bytes (measured by leaving them out, round 3).  The operand ring is
-                // free once every wave has passed its last multiply: sWb [64 m][72], sWbT [64 n][72] halfs (144-byte rows).
+                // The bf16 shadow leaves through LDS so that it reaches memory as FULL 128-byte lines: written straight from the
+                // accumulator layout it is 64-byte pieces of lines (round 3 measured 112 us of an 813 us configs[4] step for the
+                // then TWO shadows written that way).  The operand ring is free once every wave has passed its last multiply:
+                // sWb [64 m][72] halfs (144-byte rows).  (The second, transposed shadow of round 3 is gone: the forward reads
+                // this one through the transpose read, bp_bf16.h.)
                 constexpr int LDSH = 72;
-                bf16_t *sWb = smem, *sWbT = smem + 64 * LDSH;
+                bf16_t *sWb = smem;
                 __syncthreads();
                 const int ml = wm * 32 + 4 * (lane >> 5), nl = wn * 32 + (lane & 31);
 #pragma unroll
@@ -155,18 +156,14 @@ struct WgradDmaBf {
                         hb[j] = f2bf(wnew);
                         sWb[(ml + 8 * q + j) * LDSH + nl] = hb[j];
                     }
-                    *reinterpret_cast<uint2 *>(sWbT + nl * LDSH + ml + 8 * q) =
-                        make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
                 }
                 __syncthreads();
-                // 8 threads per 128-byte row, 32 rows per pass: Wb rows m0.., WbT rows n0..
+                // 8 threads per 128-byte row, 32 rows per pass: Wb rows m0..
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = (tid >> 3) + 32 * i, ch = (tid & 7) * 8;
                     const uint4 a4 = *reinterpret_cast<const uint4 *>(sWb + row * LDSH + ch);
-                    const uint4 b4 = *reinterpret_cast<const uint4 *>(sWbT + row * LDSH + ch);
                     *reinterpret_cast<uint4 *>(g.Wb + (size_t)(m0 + row) * g.ldwb + n0 + ch) = a4;
-                    *reinterpret_cast<uint4 *>(g.WbT + (size_t)(n0 + row) * g.ldwbt + m0 + ch) = b4;
                 }
             }
             if (b + stride < g.tiles_m * g.tiles_n) __syncthreads();      // the ring is refilled by the next tile's prologue
