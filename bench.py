@@ -131,7 +131,7 @@ def torch_cpu_line(W, b, budget_s=6.0):
 
 
 def kernel_source_stamp():
-    """sha256[:16] over the kernel sources, as tools/profile_r03.sh stamps its PMC summaries: tells whether a traffic
+    """sha256[:16] over the kernel sources, as tools/profile_r04.sh stamps its PMC summaries: tells whether a traffic
     figure read from profiles/ was measured on the kernels this run executes."""
     import glob
     import hashlib
@@ -180,10 +180,11 @@ def c5_line(dnnse_amd, dev, steps=40):
     # algorithmic bytes per step of the bf16 mode (lower figure): bf16 weights read by fwd and dgrad
     # (2P + 2(P - s0 s1)), fp32 W and delta read + written by the fused update (16P), bf16 shadow refresh (2P)
     alg = 22.0 * P - 2.0 * C5_LAYERS[0] * C5_LAYERS[1]
-    # HBM-side bytes of the step from the committed PMC pass (tools/profile_r03.sh): every kernel of one step summed
+    # HBM-side bytes of the step from the committed PMC pass (tools/profile_r04.sh): every kernel of one step summed
     traffic, tstamp = None, None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_c5_pmc_hbm_traffic.json")))
+        c5_file = next(f for f in ("r04_c5_pmc_hbm_traffic.json", "r03_c5_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        pm = json.load(open(os.path.join(ROOT, "profiles", c5_file)))
         tot, steps_prof = 0.0, None
         for k, v in pm["kernels"].items():
             if k.startswith(("void bp_gemm_bf16", "void bp_wgrad_dma_bf16", "bp_bias_bf16", "bp_to_bf16_both")) and "fetch_MB_corrected_x2" in v and "write_MB" in v:
@@ -194,7 +195,7 @@ def c5_line(dnnse_amd, dev, steps=40):
             note = pm.get("note", "")
             st = note.split("sha256[:16] ")[1].split(";")[0] if "sha256[:16] " in note else None
             traffic = tot / steps_prof
-            tstamp = {"source": "profiles/r03_c5_pmc_hbm_traffic.json", "sources_sha": st, "matches_current_kernel_sources": st == kernel_source_stamp() if st else None}
+            tstamp = {"source": "profiles/" + c5_file, "sources_sha": st, "matches_current_kernel_sources": st == kernel_source_stamp() if st else None}
     except Exception:
         pass
     return {"workload": "configs[4] per-GPU shape: 2827->4096x5->257, 512 frames/GPU/step, bf16 operands, fp32 master W/delta, 1 GPU",
@@ -529,9 +530,9 @@ def main():
         # algorithmic bytes of that launch: W and delta read + written (16P) + every layer's activations and dEdX read once
         alg_bytes = 16.0 * P + 4.0 * BUNCH * (sum(LAYERS[:-1]) + sum(LAYERS[1:]))
         # HBM-side bytes of that launch: NOT measured in this run (PMC collection needs its own rocprofv3 passes) but read from
-        # the committed pass of tools/profile_r03.sh, stamped with the kernel sources it was taken on
+        # the committed pass of tools/profile_r04.sh, stamped with the kernel sources it was taken on
         traffic, tstamp = None, None
-        for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
             traffic, tstamp = profiled_traffic(name, lambda k: "bp_wgrad_dma" in k and "bf16" not in k and "grid=" in k and int(k.split("grid=")[1]) > 500000)
             if traffic is not None:
                 break
@@ -539,7 +540,7 @@ def main():
         rk_ms = None
         try:
             import csv
-            rk_file = "r03_bench_kernel_stats.csv" if os.path.exists(os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")) else "r02_bench_kernel_stats.csv"
+            rk_file = next(f for f in ("r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", rk_file))):
                 if row["Name"].startswith("void bp_wgrad_dma<16, 4, 4, 256") and "true" not in row["Name"]:     # (the fused-update form)
                     rk_ms = float(row["AverageNs"]) * 1e-6
