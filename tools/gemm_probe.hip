@@ -88,6 +88,12 @@ int main(int argc, char **argv)
 #define FWDSK(NS) vs.push_back({"fwdSK" #NS " 32x64x64 w1x2 partial", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.K = H / NS; g.k_split = H / NS; g.slab_stride = (size_t)B * LDMAX; e.C = dX; \
         g.tiles_m = B / 32; g.tiles_n = H / 64; hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_PARTIAL, 1>), dim3(g.tiles_m * g.tiles_n, NS), dim3(256), 0, s, g, e); }, fl})
     FWDSK(1); FWDSK(2); FWDSK(4);
+    // round 4: LARGER tiles with the split (fewer operand bytes per flop into each CU: 24 B/clk at full MFMA rate for 32x64, 16 for
+    // 64x64, 12 for 64x128 / 128x64), still 256 workgroups; plain partial stores, i.e. WITHOUT the cross-workgroup reduction a real
+    // kernel would add -- an upper bound of what the shape can give
+#define FWDSKT(BM, BN, BK, WM, WN, NS) vs.push_back({"fwdSK" #NS " " #BM "x" #BN "x" #BK " w" #WM "x" #WN " partial", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.K = H / NS; g.k_split = H / NS; g.slab_stride = (size_t)B * LDMAX; e.C = dX; \
+        g.tiles_m = B / BM; g.tiles_n = H / BN; hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, true, false, EPI_PARTIAL, 1>), dim3(g.tiles_m * g.tiles_n, NS), dim3(256), 0, s, g, e); }, fl})
+    FWDSKT(64, 64, 64, 2, 2, 2); FWDSKT(64, 64, 32, 2, 2, 2); FWDSKT(64, 128, 32, 2, 2, 4); FWDSKT(128, 64, 32, 2, 2, 4); FWDSKT(64, 128, 64, 2, 2, 4); FWDSKT(64, 64, 64, 2, 2, 4); FWDSKT(128, 128, 32, 2, 2, 8);
     // same kernel, every k-row of W aliased to row 0 (ldb = 0): operands always hit L2 -> isolates HBM/MALL latency
     vs.push_back({"fwdL2 32x64x64 w1x2 pf1 (ldb=0)", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.ldb = 0; go<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>(s, g, e, B, H, 0); }, fl});
     FWD(32, 64, 64, 1, 2, 1); FWD(32, 64, 128, 1, 2, 1); FWD(64, 32, 128, 2, 1, 1); FWD(32, 64, 64, 1, 2, 2); FWD(32, 64, 32, 1, 2, 1); FWD(32, 64, 32, 1, 2, 2);
