@@ -39,6 +39,7 @@ struct BfGemmArgs {
     const bf16_t *A, *B;       // A [M][lda], B [N][ldb], both k-contiguous; rows padded to 64, k padded to 64 (zeros)
     int lda, ldb, K;           // K: multiple of 64
     int tiles_m, tiles_n;
+    int k_rot;                 // LDS-DMA form: k-tile offset between the m-tiles of one n-tile
 };
 struct BfEpiArgs {
     int m_limit, n_limit, n_true;      // rows / cols that exist (padded extents), unpadded column count
@@ -66,15 +67,31 @@ static constexpr int BF_NPF = 3;                                     // k-tiles 
 static constexpr int BF_LDB = 96;
 typedef short bf_v4s __attribute__((ext_vector_type(4)));
 typedef short bf_v8s __attribute__((ext_vector_type(8)));
-template <int EPI, int BM, bool BKN = false>
-__global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
+typedef float bf_f32x4 __attribute__((ext_vector_type(4)));
+// DMA (BM = 128 only; the 4096-wide GEMMs of configs[4]): the operand tiles go global -> LDS by global_load_lds_dwordx4 instead of
+// through registers + ds_write_b128 (13 LDS cycles per wave instruction, 312 per k-tile: more than the tile's 256 MFMA cycles).
+// One k-tile = 192 rows (128 of A, 64 of B) x 128 bytes = 24 pieces of 1 KiB (8 rows each), 6 per wave; ring of 4 stages, three
+// tiles in flight, ONE raw s_barrier per k-tile behind a counted s_waitcnt vmcnt.  Bank swizzle in the SOURCE address of the DMA:
+// chunk c (16 bytes) of row r sits in slot c ^ ((r>>1)&7) (ds_read_b128 fragments: the 16 lanes of a read group cover both row
+// parities x 8 slots), and for the [k][n] tile of the forward chunk c of k-row k in slot c ^ (4*((k>>1)&1)) (ds_read_b64_tr_b16:
+// the 4 k-rows x 64 bytes of a half-wave cover all 64 banks).  Every LDS read of the loop is inline asm and every wait is counted
+// by hand (reads return in order): the fragments of k-step q+1 are in flight while the MFMAs of step q run, the six DMA pieces of
+// tile t+3 are issued between them.  (Through the builtin, the compiler puts s_waitcnt vmcnt(0) in front of every transpose read
+// -- it orders them behind ALL pending LDS-DMA -- which serialises the loop: 70.9 us.)  tools/bf16_gemm_probe.hip holds the
+// measured steps from the register-staged loop (35.5-36.9 us per 512 x 4096 x 4096 GEMM) to this one (22.3-23.3 us).
+template <int N> __device__ __forceinline__ void bf_lgkm3(bf_f32x4 &a, bf_f32x4 &b, bf_f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
+template <int N> __device__ __forceinline__ void bf_lgkm4(bf_f32x4 &a, bf_f32x4 &b, bf_v4s &c, bf_v4s &d) { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N)); }
+template <int EPI, int BM, bool BKN = false, bool DMA = false>
+__global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
 {
+    static_assert(!DMA || BM == 128, "the LDS-DMA loop is written for 128 x 64 tiles");
     constexpr int NTHR = BM == 32 ? 128 : 256, ROWS = BM + BF_BN, NCHK = ROWS * 8 / NTHR;     // 16-byte chunks per thread and tile
     constexpr int TMB = BM == 128 ? 2 : 1;                                                      // 32x32 blocks per wave along m
     constexpr int NCHK_A = BM * 8 / NTHR;                                                       // chunks i < NCHK_A belong to A, the rest to B
     constexpr int STAGE_H = BKN ? BM * BF_LDS + BF_BK * BF_LDB : ROWS * BF_LDS;                 // halfs per LDS stage
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * STAGE_H];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = (BM >= 64) ? wave >> 1 : 0, wn = wave & 1;
+    constexpr int DMA_STAGE = 192 * 128, DMA_ST = 4;                                            // bytes per stage, ring length
+    __shared__ __attribute__((aligned(1024))) bf16_t smem[DMA ? DMA_ST * DMA_STAGE / 2 : 2 * STAGE_H];
+    const int tid = threadIdx.x, lane = tid & 63, wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6, wm = (BM >= 64) ? wave >> 1 : 0, wn = wave & 1;
     // XCD-aware tile map (block b runs on XCD b % 8): the workgroups that share a B panel (same tile_n, all tile_m)
     // sit on one XCD, so the panel is fetched into that XCD's L2 once instead of eight times
     int tile_m, tile_n;
@@ -133,6 +150,88 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const Bf
 #pragma unroll
         for (int r = 0; r < 16; ++r) accs[b][r] = 0.0f;
     const int nt = g.K / BF_BK;
+    if constexpr (DMA) {
+        typedef __attribute__((address_space(3))) void *lds_ptr;
+        typedef const __attribute__((address_space(1))) void *glb_ptr;
+        char *sm = reinterpret_cast<char *>(smem);
+        // this wave's six pieces of a tile: rows 8*(6*wave+i) .. +7 of the 192-row image; lane -> row + (lane>>3), slot lane&7
+        const bf16_t *psrc[6]; size_t pstep[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int r = 8 * (wave * 6 + i) + (lane >> 3);
+            if (r < BM || !BKN) {
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                psrc[i] = (r < BM ? g.A + (size_t)(m0 + r) * g.lda : g.B + (size_t)(n0 + r - BM) * g.ldb) + c * 8; pstep[i] = BF_BK;
+            } else {
+                const int k = r - BM, c = (lane & 7) ^ (4 * ((k >> 1) & 1));
+                psrc[i] = g.B + (size_t)k * g.ldb + n0 + c * 8; pstep[i] = (size_t)BF_BK * g.ldb;
+            }
+        }
+        // the workgroups that share a B panel (the m-tiles of one n-tile, same XCD) walk k out of phase, BF_ROT tiles apart: each
+        // line of the panel is then pulled from HBM by ONE of them and found in L2 by the others, instead of four requests for a line
+        // that is still on its way (cold weights: 30.3 -> 26.5 us in tools/bf16_gemm_probe.hip)
+        const int rot = (tile_m * g.k_rot) % nt;
+#define BF_PIECE(i, t, st)                                                                                          \
+        do { int tt_ = ((t) < nt ? (t) : nt - 1) + rot;     /* past the end: a duplicate into a stage nobody reads */   \
+             if (tt_ >= nt) tt_ -= nt;                                                                              \
+             __builtin_amdgcn_global_load_lds((glb_ptr)(psrc[i] + (size_t)tt_ * pstep[i]),                          \
+                                              (lds_ptr)(sm + (st) * DMA_STAGE + (wave * 6 + (i)) * 1024), 16, 0, 0); } while (0)
+        // fragment addresses (bytes in LDS, stage 0): row r, chunk 2q+h -> r*128 + 16*(h ^ (s&1)) + 32*(q ^ (s>>1)), s = (r>>1)&7
+        const int ra = wm * 64 + (lane & 31), rb = BM + wn * 32 + (lane & 31), hh = lane >> 5;
+        const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)sm;
+        const int jj4 = (lane & 15) >> 2, cb = 4 * wn + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+        unsigned aq[4], bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            aq[q] = lds0 + ra * 128 + 16 * (hh ^ (sa & 1)) + 32 * (q ^ (sa >> 1));
+            bq[q] = BKN ? lds0 + BM * 128 + (16 * q + 8 * hh + jj4) * 128 + 16 * (cb ^ (4 * ((jj4 >> 1) & 1))) + 8 * (lane & 1)
+                        : lds0 + rb * 128 + 16 * (hh ^ (sb & 1)) + 32 * (q ^ (sb >> 1));
+        }
+        bf_f32x4 fa0[4], fa1[4], fb[4]; bf_v4s flo[4], fhi[4];
+        constexpr int NRD = BKN ? 4 : 3;                    // LDS reads per k-step
+#define BF_READS(so, q)                                                                                             \
+        do { asm volatile("ds_read_b128 %0, %1" : "=v"(fa0[q]) : "v"(aq[q] + (so)));                                \
+             if constexpr (BKN) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(flo[q]) : "v"(bq[q] + (so)));    \
+                                  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(fhi[q]) : "v"(bq[q] + (so))); } \
+             else asm volatile("ds_read_b128 %0, %1" : "=v"(fb[q]) : "v"(bq[q] + (so)));                            \
+             asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(fa1[q]) : "v"(aq[q] + (so))); } while (0)
+#define BF_ARRIVED(q, N) do { if constexpr (BKN) bf_lgkm4<(N)>(fa0[q], fa1[q], flo[q], fhi[q]); else bf_lgkm3<(N)>(fa0[q], fa1[q], fb[q]); } while (0)
+#pragma unroll
+        for (int t = 0; t < DMA_ST - 1; ++t)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) BF_PIECE(i, t, t);
+        for (int t = 0; t < nt; ++t) {
+            const unsigned so = (unsigned)((t % DMA_ST) * DMA_STAGE);
+            const int stn = (t + DMA_ST - 1) % DMA_ST;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_ST - 2) * 6) : "memory");       // tile t has landed (the DMA_ST-2 tiles behind it may be in flight)
+            __builtin_amdgcn_s_barrier();                            // ... for every wave; and the stage of tile t-1 is free for tile t+DMA_ST-1
+            __builtin_amdgcn_sched_barrier(0);
+            BF_READS(so, 0); BF_READS(so, 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) BF_ARRIVED(q, NRD); else BF_ARRIVED(q, 0);          // behind step q: the reads of step q+1
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8_t bf_;
+                if constexpr (BKN) bf_ = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(flo[q], fhi[q], 0, 1, 2, 3, 4, 5, 6, 7));
+                else bf_ = __builtin_bit_cast(bf16x8_t, fb[q]);
+                accs[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa0[q]), bf_, accs[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < 2) BF_PIECE(2 * q, t + DMA_ST - 1, stn); else BF_PIECE(2 + q, t + DMA_ST - 1, stn);
+                __builtin_amdgcn_sched_barrier(0);
+                accs[TMB - 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa1[q]), bf_, accs[TMB - 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < 2) BF_PIECE(2 * q + 1, t + DMA_ST - 1, stn);
+                if (q + 2 < 4) BF_READS(so, q + 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the clamped duplicates of the last three iterations
+#undef BF_PIECE
+#undef BF_READS
+#undef BF_ARRIVED
+    } else {
     // three register images of a tile, always addressed by name (a runtime-indexed array would live in scratch)
     struct Img { uint4 v[NCHK]; };
     Img r0, r1, r2;
@@ -187,8 +286,16 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const Bf
 #undef BF_STORE
 #undef BF_ITER
 
+    }
+
     // ---- epilogue
-    if (n >= e.n_limit) return;
+    // DMA form: the two bf16 copies of the tile leave through LDS as whole 128-byte lines (8 x 16-byte stores per thread instead of
+    // 32 two-byte and 16 eight-byte ones straight from the accumulator layout: the store ISSUE was a third of the kernel).  The ring
+    // is free: every wave is past its last fragment read once the barrier below is passed, and no DMA is in flight.
+    constexpr int OC_LD = 72, OT_LD = 136;                    // halfs per row of the staged C [128][64] and CT [64][128] tiles
+    bf16_t *oc = smem, *ot = smem + 128 * OC_LD;
+    if constexpr (DMA) __syncthreads();
+    else if (n >= e.n_limit) return;
 #pragma unroll
     for (int blk = 0; blk < TMB; ++blk) {
     const f32x16 &acc = accs[blk];
@@ -246,12 +353,35 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, 2) void bp_gemm_bf16(const Bf
         bf16_t hb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) hb[j] = f2bf(v[j]);
+        const uint2 pk = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+        if constexpr (DMA) {
+            const int ml = mq - m0, nl = n - n0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oc[(ml + j) * OC_LD + nl] = hb[j];
+            *reinterpret_cast<uint2 *>(ot + nl * OT_LD + ml) = pk;
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (mq + j < e.m_limit) e.C[(size_t)(mq + j) * e.ldc + n] = hb[j];
-        const uint2 pk = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
         if (e.CT) *reinterpret_cast<uint2 *>(e.CT + (size_t)n * e.ldct + mq) = pk;     // (the weights keep ONE shadow: no transposed copy)
+        }
     }
+    }
+    if constexpr (DMA) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                          // C: 128 rows x 8 chunks of 16 bytes
+            const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+            if (m0 + row < e.m_limit)
+                *reinterpret_cast<uint4 *>(e.C + (size_t)(m0 + row) * e.ldc + n0 + ch * 8) = *reinterpret_cast<const uint4 *>(oc + row * OC_LD + ch * 8);
+        }
+        if (e.CT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                      // CT: 64 rows x 16 chunks
+                const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+                *reinterpret_cast<uint4 *>(e.CT + (size_t)(n0 + row) * e.ldct + m0 + ch * 8) = *reinterpret_cast<const uint4 *>(ot + row * OT_LD + ch * 8);
+            }
+        }
     }
 }
 

@@ -575,6 +575,17 @@ static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int 
     static const bool no128 = getenv("BP_BF16_NO128") != nullptr;                 // development A/B switch
     if (!no128 && M % 128 == 0 && (M / 128) * g.tiles_n >= 256) {                 // 128-row tiles still fill the chip
         g.tiles_m = M / 128;
+        static const bool no_dma = getenv("BP_BF16_GEMM_NO_DMA") != nullptr;      // development A/B switch
+        if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_DGRAD) {              // LDS-DMA staged loop (bp_bf16.h)
+            if (!no_dma && (g.tiles_n & 7) == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && e.ldc % 8 == 0 && e.ldct % 8 == 0 && e.n_limit == N) {
+                // k-tile offset between the m-tiles that share a weight panel (measured in the step, configs[4]: forward -- weights
+                // cold behind the update launch -- 38.1 us in phase, 33.7 a quarter of K apart; dgrad -- weights read by the forward
+                // 0.3 ms earlier -- 31.4 in phase, 30.4 two tiles apart, 32.3 a quarter apart)
+                g.k_rot = EPI == BEPI_FWD_HIDDEN ? (g.K / 64) / g.tiles_m : 2;
+                hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128, BKN, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128, BKN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
     } else if ((M / 64) * g.tiles_n >= 512) {
         g.tiles_m = M / 64;

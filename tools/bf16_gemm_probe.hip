@@ -1,0 +1,717 @@
+// tools/bf16_gemm_probe.hip -- development probe (not part of the library): LDS-DMA forms of the bf16 GEMM of configs[4]
+// (C[512][4096] = A[512][4096] . B[4096][4096]^T, both operands k-contiguous = the dgrad form), against the shipped register-staged
+// bp_gemm_bf16<.,128> (35.5-36.9 us per launch, profiles/r04_bf16_c5_kernel_stats.csv).  Every variant is checked against a plain
+// one-thread-per-output kernel.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/bf16_gemm_probe tools/bf16_gemm_probe.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <type_traits>
+#include <stdint.h>
+typedef uint16_t bf16_t;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+template <int N> struct VmWait { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory"); } };
+template <int N> struct LgkmWait { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N < 15 ? N : 15) : "memory"); } };
+typedef __attribute__((address_space(3))) void *lds_ptr;
+typedef const __attribute__((address_space(1))) void *glb_ptr;
+
+static __host__ __device__ inline float bf2f(bf16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline bf16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+
+__global__ void touch(const uint4 *p, size_t n, float *sink)
+{
+    uint4 s = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = p[i]; s.x ^= v.x; s.y ^= v.y; s.z ^= v.z; s.w ^= v.w; }
+    if ((s.x ^ s.y ^ s.z ^ s.w) == 0x12345677u) sink[0] = 0.f;
+}
+__global__ void ref_gemm(const bf16_t *A, const bf16_t *B, float *C, int M, int N, int K)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N || m >= M) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += bf2f(A[(size_t)m * K + k]) * bf2f(B[(size_t)n * K + k]);
+    C[(size_t)m * N + n] = s;
+}
+
+// 128 x 64 x 64 tiles, 4 waves (2 x 2, wave tile 64 x 32), operands global -> LDS by global_load_lds_dwordx4 (1 KiB per wave
+// instruction = 8 rows of 128 bytes), ring of ST stages with D = ST-1 tiles in flight.  LDS image of a tile: 192 rows (128 of A,
+// 64 of B) x 128 bytes; 16-byte chunk c of row r sits in slot c ^ ((r>>1)&7) (the swizzle is applied to the SOURCE address of
+// the DMA; conflict-free ds_read_b128 fragments: the 16 lanes of a read group cover both row parities x 8 slot values).
+// MODE 0: per k-tile  wait+barrier, issue the 6 DMA pieces of tile t+D, then 12 fragment reads, then 8 MFMAs
+// MODE 1: DMA pieces and fragment reads interleaved with the MFMAs (pinned)
+template <int ST, int MODE, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_dma(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n)
+{
+    constexpr int STAGE = 192 * 128, D = ST - 1;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    const bf16_t *src[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int r = 8 * (wave * 6 + i) + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + c * 8;
+    }
+    const int nt = K / 64;
+    auto issue_piece = [&](int i, int t, int st) {
+        if constexpr (ABL & 1) { if (t >= D) return; }
+        const int tt = t < nt ? t : nt - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * 64), (lds_ptr)(smem + st * STAGE + (wave * 6 + i) * 1024), 16, 0, 0);
+    };
+    // fragment addresses: row r, chunk 2q+h -> r*128 + 16*(h ^ (s&1)) + 32*(q ^ (s>>1)), s = (r>>1)&7
+    const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 32 + (lane & 31), h = lane >> 5;
+    const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+    const int abase = ra * 128 + 16 * (h ^ (sa & 1)), bbase = rb * 128 + 16 * (h ^ (sb & 1));
+    int aq[4], bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { aq[q] = abase + 32 * (q ^ (sa >> 1)); bq[q] = bbase + 32 * (q ^ (sb >> 1)); }
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_piece(i, t, t);
+    bf16x8_t a0[4], a1[4], b[4];
+    for (int t = 0; t < nt; ++t) {
+        const char *base = smem + (t % ST) * STAGE;
+        const int stn = (t + D) % ST;
+        if constexpr (!(ABL & 1)) VmWait<(D - 1) * 6>::go(); else VmWait<0>::go();
+        if constexpr (!(ABL & 4)) __builtin_amdgcn_s_barrier();
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) issue_piece(i, t + D, stn);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a0[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q]);
+                a1[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q] + 4096);
+                b[q] = *reinterpret_cast<const bf16x8_t *>(base + bq[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[q], b[q], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[q], b[q], acc[1], 0, 0, 0);
+            }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL & 2) { if (t == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a0[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q]); b[q] = *reinterpret_cast<const bf16x8_t *>(base + bq[q]); a1[q] = a0[q]; } } }
+            else
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                a0[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q]);
+                b[q] = *reinterpret_cast<const bf16x8_t *>(base + bq[q]);
+                a1[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q] + 4096);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[q], b[q], acc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < 2) issue_piece(2 * q, t + D, stn); else issue_piece(2 + q, t + D, stn);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[q], b[q], acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q < 2) issue_piece(2 * q + 1, t + D, stn);
+                if (q + 2 < 4 && !(ABL & 2)) {
+                    a0[q + 2] = *reinterpret_cast<const bf16x8_t *>(base + aq[q + 2]);
+                    b[q + 2] = *reinterpret_cast<const bf16x8_t *>(base + bq[q + 2]);
+                    a1[q + 2] = *reinterpret_cast<const bf16x8_t *>(base + aq[q + 2] + 4096);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // epilogue: lane -> column, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the 32x32 block
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            C[(size_t)m * ldc + n] = acc[i][r];
+        }
+}
+
+// The same tile with EIGHT waves: waves 0-3 take k-steps {0,1} of every 64-deep k-tile, waves 4-7 k-steps {2,3} (same 2 x 2 wave
+// grid, same 64 x 32 wave tile, own accumulators; one LDS reduction at the end).  Two waves per SIMD: while one sits in the issue
+// of a DMA piece or an LDS read, the other feeds the matrix pipe.  3 DMA pieces per wave and k-tile.
+template <int ST, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_dma8(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n)
+{
+    constexpr int STAGE = 192 * 128, D = ST - 1;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    const bf16_t *src[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int r = 8 * (wave * 3 + i) + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + c * 8;
+    }
+    const int nt = K / 64;
+    auto issue_piece = [&](int i, int t, int st) {
+        if constexpr (ABL & 1) { if (t >= D) return; }
+        const int tt = t < nt ? t : nt - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * 64), (lds_ptr)(smem + st * STAGE + (wave * 3 + i) * 1024), 16, 0, 0);
+    };
+    const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 32 + (lane & 31), h = lane >> 5;
+    const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+    const int abase = ra * 128 + 16 * (h ^ (sa & 1)), bbase = rb * 128 + 16 * (h ^ (sb & 1));
+    int aq[2], bq[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { aq[q] = abase + 32 * ((2 * kg + q) ^ (sa >> 1)); bq[q] = bbase + 32 * ((2 * kg + q) ^ (sb >> 1)); }
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) issue_piece(i, t, t);
+    bf16x8_t a0[2], a1[2], b[2];
+    for (int t = 0; t < nt; ++t) {
+        const char *base = smem + (t % ST) * STAGE;
+        const int stn = (t + D) % ST;
+        if constexpr (!(ABL & 1)) VmWait<(D - 1) * 3>::go(); else VmWait<0>::go();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a0[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q]);
+            b[q] = *reinterpret_cast<const bf16x8_t *>(base + bq[q]);
+            a1[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q] + 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(0, t + D, stn);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[0], b[0], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(1, t + D, stn);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[0], b[0], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_piece(2, t + D, stn);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[1], b[1], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[1], b[1], acc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // k-group 1 hands its partial sums to k-group 0 through LDS (the ring is free after one more barrier)
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);
+    if (kg == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave & 3) * 2 + i) * 16 + r) * 64 + lane] = acc[i][r];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            C[(size_t)m * ldc + n] = acc[i][r] + red[((wave * 2 + i) * 16 + r) * 64 + lane];
+        }
+}
+
+// 128-deep k-tiles (half the barriers): rows of 256 bytes, slot = chunk ^ (row & 15); 1 KiB DMA piece = 4 rows; 48 KB per stage.
+// RA = fragment read-ahead in k-steps.
+template <int ST, int RA>
+__global__ __launch_bounds__(256) void gemm_dma128(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n)
+{
+    constexpr int STAGE = 192 * 256, D = ST - 1, NP = 12;          // 48 pieces per tile, 12 per wave
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    // piece j of a tile = rows 4j .. 4j+3; this wave's pieces: j = wave*12 + i.  Row r = 4j + (lane>>4), slot lane&15.
+    const bf16_t *src[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int r = 4 * (wave * NP + i) + (lane >> 4), c = (lane & 15) ^ (r & 15);
+        src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + c * 8;
+    }
+    const int nt = K / 128;
+    auto issue_piece = [&](int i, int t, int st) {
+        const int tt = t < nt ? t : nt - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * 128), (lds_ptr)(smem + st * STAGE + (wave * NP + i) * 1024), 16, 0, 0);
+    };
+    const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 32 + (lane & 31), h = lane >> 5;
+    const int sa = ra & 15, sb = rb & 15;
+    const int abase = ra * 256 + 16 * (h ^ (sa & 1)), bbase = rb * 256 + 16 * (h ^ (sb & 1));
+    int aq[8], bq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { aq[q] = abase + 32 * (q ^ (sa >> 1)); bq[q] = bbase + 32 * (q ^ (sb >> 1)); }
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) issue_piece(i, t, t);
+    bf16x8_t a0[8], a1[8], b[8];
+    for (int t = 0; t < nt; ++t) {
+        const char *base = smem + (t % ST) * STAGE;
+        const int stn = (t + D) % ST;
+        VmWait<(D - 1) * NP>::go();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < RA; ++q) {
+            a0[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q]);
+            b[q] = *reinterpret_cast<const bf16x8_t *>(base + bq[q]);
+            a1[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q] + 32 * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[q], b[q], acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(q, t + D, stn);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[q], b[q], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 4) issue_piece(8 + q, t + D, stn);
+            if (q + RA < 8) {
+                a0[q + RA] = *reinterpret_cast<const bf16x8_t *>(base + aq[q + RA]);
+                b[q + RA] = *reinterpret_cast<const bf16x8_t *>(base + bq[q + RA]);
+                a1[q + RA] = *reinterpret_cast<const bf16x8_t *>(base + aq[q + RA] + 32 * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            C[(size_t)m * ldc + n] = acc[i][r];
+        }
+}
+
+// The forward's form: B lies [k][n] in memory (the ONE weight shadow Wb[prev][cur]); its tile is 64 k-rows of 128 bytes, chunk c of
+// k-row k in slot c ^ (4*((k>>1)&1)), fragments through ds_read_b64_tr_b16 (two per fragment: k-rows j..j+3 and j+4..j+7).
+typedef short v4s __attribute__((ext_vector_type(4)));
+template <int ST, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_dma_bkn(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n)
+{
+    constexpr int STAGE = 192 * 128, D = ST - 1;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    const bf16_t *src[6]; size_t step[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int r = 8 * (wave * 6 + i) + (lane >> 3);
+        if (r < 128) { const int c = (lane & 7) ^ ((r >> 1) & 7); src[i] = A + (size_t)(m0 + r) * lda + c * 8; step[i] = 64; }
+        else { const int k = r - 128, c = (lane & 7) ^ (4 * ((k >> 1) & 1)); src[i] = B + (size_t)k * ldb + n0 + c * 8; step[i] = (size_t)64 * ldb; }
+    }
+    const int nt = K / 64;
+    auto issue_piece = [&](int i, int t, int st) {
+        if constexpr (ABL & 1) { if (t >= D) return; }
+        const int tt = t < nt ? t : nt - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * step[i]), (lds_ptr)(smem + st * STAGE + (wave * 6 + i) * 1024), 16, 0, 0);
+    };
+    const int ra = wm * 64 + (lane & 31), h = lane >> 5;
+    const int sa = (ra >> 1) & 7;
+    const int abase = ra * 128 + 16 * (h ^ (sa & 1));
+    int aq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aq[q] = abase + 32 * (q ^ (sa >> 1));
+    const int j = (lane & 15) >> 2, cb = 4 * wn + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+    const int tr0 = 128 * 128 + (8 * h + j) * 128 + 16 * (cb ^ (4 * ((j >> 1) & 1))) + 8 * (lane & 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_piece(i, t, t);
+    bf16x8_t a0[4], a1[4], b[4];
+    typedef __attribute__((address_space(3))) v4s *lds4;
+    // the transpose reads go out as inline asm: through the builtin the compiler orders them behind ALL pending LDS-DMA (s_waitcnt
+    // vmcnt(0) in front of each), which serialises the loop (70.9 us).  Their arrival is awaited by hand (wait_b).
+    v4s blo[4], bhi[4];
+    auto bfrag_issue = [&](const char *base, int q) {
+        const unsigned a = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)(base + tr0 + q * 2048);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[q]) : "v"(a));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(bhi[q]) : "v"(a));
+    };
+    auto wait_b = [&](int q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[q]), "+v"(bhi[q])); b[q] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[q], bhi[q], 0, 1, 2, 3, 4, 5, 6, 7)); };
+    for (int t = 0; t < nt; ++t) {
+        const char *base = smem + (t % ST) * STAGE;
+        const int stn = (t + D) % ST;
+        if constexpr (ABL & 1) VmWait<0>::go(); else VmWait<(D - 1) * 6>::go();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a0[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q]);
+            bfrag_issue(base, q);
+            a1[q] = *reinterpret_cast<const bf16x8_t *>(base + aq[q] + 4096);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wait_b(q);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[q], b[q], acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 2) issue_piece(2 * q, t + D, stn); else issue_piece(2 + q, t + D, stn);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[q], b[q], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 2) issue_piece(2 * q + 1, t + D, stn);
+            if (q + 2 < 4) {
+                a0[q + 2] = *reinterpret_cast<const bf16x8_t *>(base + aq[q + 2]);
+                bfrag_issue(base, q + 2);
+                a1[q + 2] = *reinterpret_cast<const bf16x8_t *>(base + aq[q + 2] + 4096);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            C[(size_t)m * ldc + n] = acc[i][r];
+        }
+}
+
+// Version 2 of the 64-deep kernel: EVERY LDS read is inline asm and every wait is counted by hand (reads return in order):
+// the fragments of k-step q+1 (and q+2 with RA = 2) stay in flight while the MFMAs of step q run.  BKN selects the forward's form.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int N> __device__ __forceinline__ void lgkm_wait3(f32x4v &a, f32x4v &b, f32x4v &c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
+template <int N> __device__ __forceinline__ void lgkm_wait4(f32x4v &a, f32x4v &b, v4s &c, v4s &d) { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N)); }
+template <int ST, bool BKN, int RA>
+__global__ __launch_bounds__(256) void gemm_dma_v2(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n,
+                                                   const uint4 *pf = nullptr, size_t pf_chunks = 0, int stag = 0)
+{
+    if ((int)blockIdx.x >= tiles_m * tiles_n) {
+        // workgroups behind the tiles: pull the NEXT launch's weights through the memory-side cache (results discarded)
+        const size_t nb = gridDim.x - tiles_m * tiles_n, b = blockIdx.x - tiles_m * tiles_n;
+        uint4 s = make_uint4(0, 0, 0, 0);
+        for (size_t i = b * 256 + threadIdx.x; i < pf_chunks; i += nb * 256 * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const size_t j = i + u * nb * 256; v[u] = j < pf_chunks ? pf[j] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x ^= v[u].x; s.y ^= v[u].y; s.z ^= v[u].z; s.w ^= v[u].w; }
+        }
+        if ((s.x ^ s.y ^ s.z ^ s.w) == 0x12345677u) C[0] = 0.f;
+        return;
+    }
+    constexpr int STAGE = 192 * 128, D = ST - 1;
+    constexpr int NRD = BKN ? 4 : 3;                       // LDS read instructions per k-step
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    const bf16_t *src[6]; size_t step[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int r = 8 * (wave * 6 + i) + (lane >> 3);
+        if (r < 128 || !BKN) { const int c = (lane & 7) ^ ((r >> 1) & 7); src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + c * 8; step[i] = 64; }
+        else { const int k = r - 128, c = (lane & 7) ^ (4 * ((k >> 1) & 1)); src[i] = B + (size_t)k * ldb + n0 + c * 8; step[i] = (size_t)64 * ldb; }
+    }
+    const int nt = K / 64;
+    const int rot = stag >= 0 ? ((blockIdx.x & 7) * stag) % nt : (tile_m * (-stag)) % nt;   // stag < 0: rotate by m-tile (the sharers of a B panel)
+    auto issue_piece = [&](int i, int t, int st) {
+        int tt = t < nt ? t : nt - 1;
+        tt += rot; if (tt >= nt) tt -= nt;                  // k-tiles in rotated order (per XCD): the XCDs stream different stripes of B
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * step[i]), (lds_ptr)(smem + st * STAGE + (wave * 6 + i) * 1024), 16, 0, 0);
+    };
+    const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 32 + (lane & 31), h = lane >> 5;
+    const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)smem;
+    unsigned aq[4], bq[4];
+    const int j = (lane & 15) >> 2, cb = 4 * wn + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        aq[q] = lds0 + ra * 128 + 16 * (h ^ (sa & 1)) + 32 * (q ^ (sa >> 1));
+        bq[q] = BKN ? lds0 + 128 * 128 + (16 * q + 8 * h + j) * 128 + 16 * (cb ^ (4 * ((j >> 1) & 1))) + 8 * (lane & 1)
+                    : lds0 + rb * 128 + 16 * (h ^ (sb & 1)) + 32 * (q ^ (sb >> 1));
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_piece(i, t, t);
+    f32x4v a0[4], a1[4], bb[4]; v4s blo[4], bhi[4];
+    auto reads = [&](unsigned so, int q) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a0[q]) : "v"(aq[q] + so));
+        if constexpr (BKN) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[q]) : "v"(bq[q] + so));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(bhi[q]) : "v"(bq[q] + so));
+        } else asm volatile("ds_read_b128 %0, %1" : "=v"(bb[q]) : "v"(bq[q] + so));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[q]) : "v"(aq[q] + so));
+    };
+#define ARRIVED(q, N) do { if constexpr (BKN) lgkm_wait4<(N)>(a0[q], a1[q], blo[q], bhi[q]); else lgkm_wait3<(N)>(a0[q], a1[q], bb[q]); } while (0)
+    auto bfrag = [&](int q) {
+        if constexpr (BKN) return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[q], bhi[q], 0, 1, 2, 3, 4, 5, 6, 7));
+        else return __builtin_bit_cast(bf16x8_t, bb[q]);
+    };
+    for (int t = 0; t < nt; ++t) {
+        const unsigned so = (unsigned)((t % ST) * STAGE);
+        const int stn = (t + D) % ST;
+        VmWait<(D - 1) * 6>::go();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < RA; ++q) reads(so, q);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // pending behind step q at this point: steps q+1 .. min(q+RA-1, 3)
+            if (q + RA - 1 <= 3) ARRIVED(q, (RA - 1) * NRD);
+            else if (q == 3) ARRIVED(q, 0);
+            else ARRIVED(q, NRD);                                        // (RA = 3, q = 2: only step 3 behind)
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8_t bf = bfrag(q);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0[q]), bf, acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 2) issue_piece(2 * q, t + D, stn); else issue_piece(2 + q, t + D, stn);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q]), bf, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q < 2) issue_piece(2 * q + 1, t + D, stn);
+            if (q + RA < 4) reads(so, q + RA);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            C[(size_t)m * ldc + n] = acc[i][r];
+        }
+}
+
+// Version 3: the barrier of tile t+1 sits in the MIDDLE of tile t (after k-step 1); k-steps 2 and 3 then carry the DMA of tile t+3
+// and the first two fragment fetches of tile t+1, so no MFMA waits behind a barrier + LDS round trip.
+template <int ST, bool BKN>
+__global__ __launch_bounds__(256) void gemm_dma_v3(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n)
+{
+    constexpr int STAGE = 192 * 128, D = ST - 1;
+    constexpr int NRD = BKN ? 4 : 3;                       // LDS read instructions per k-step
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    const bf16_t *src[6]; size_t step[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int r = 8 * (wave * 6 + i) + (lane >> 3);
+        if (r < 128 || !BKN) { const int c = (lane & 7) ^ ((r >> 1) & 7); src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + c * 8; step[i] = 64; }
+        else { const int k = r - 128, c = (lane & 7) ^ (4 * ((k >> 1) & 1)); src[i] = B + (size_t)k * ldb + n0 + c * 8; step[i] = (size_t)64 * ldb; }
+    }
+    const int nt = K / 64;
+    auto issue_piece = [&](int i, int t, int st) {
+        int tt = t < nt ? t : nt - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * step[i]), (lds_ptr)(smem + st * STAGE + (wave * 6 + i) * 1024), 16, 0, 0);
+    };
+    const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 32 + (lane & 31), h = lane >> 5;
+    const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)smem;
+    unsigned aq[4], bq[4];
+    const int j = (lane & 15) >> 2, cb = 4 * wn + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        aq[q] = lds0 + ra * 128 + 16 * (h ^ (sa & 1)) + 32 * (q ^ (sa >> 1));
+        bq[q] = BKN ? lds0 + 128 * 128 + (16 * q + 8 * h + j) * 128 + 16 * (cb ^ (4 * ((j >> 1) & 1))) + 8 * (lane & 1)
+                    : lds0 + rb * 128 + 16 * (h ^ (sb & 1)) + 32 * (q ^ (sb >> 1));
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_piece(i, t, t);
+    f32x4v a0[4], a1[4], bb[4]; v4s blo[4], bhi[4];
+    auto reads = [&](unsigned so, int q) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a0[q]) : "v"(aq[q] + so));
+        if constexpr (BKN) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[q]) : "v"(bq[q] + so));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(bhi[q]) : "v"(bq[q] + so));
+        } else asm volatile("ds_read_b128 %0, %1" : "=v"(bb[q]) : "v"(bq[q] + so));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[q]) : "v"(aq[q] + so));
+    };
+#define ARRIVED(q, N) do { if constexpr (BKN) lgkm_wait4<(N)>(a0[q], a1[q], blo[q], bhi[q]); else lgkm_wait3<(N)>(a0[q], a1[q], bb[q]); } while (0)
+    auto bfrag = [&](int q) {
+        if constexpr (BKN) return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[q], bhi[q], 0, 1, 2, 3, 4, 5, 6, 7));
+        else return __builtin_bit_cast(bf16x8_t, bb[q]);
+    };
+    static_assert(ST == 4, "ring of 4");
+    VmWait<12>::go();
+    __builtin_amdgcn_s_barrier();
+    reads(0u, 0); reads(0u, 1);
+    for (int t = 0; t < nt; ++t) {
+        const unsigned so = (unsigned)((t & 3) * STAGE), so1 = (unsigned)(((t + 1) & 3) * STAGE);
+        const int stn = (t + 3) & 3;
+#define MM(q, P0, P1, P2, RD)                                                                                                     \
+        do {                                                                                                                      \
+            ARRIVED(q, NRD);                                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            const bf16x8_t bf = bfrag(q);                                                                                         \
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0[q]), bf, acc[0], 0, 0, 0);           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            if (P0 >= 0) issue_piece(P0 < 0 ? 0 : P0, t + 3, stn);                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q]), bf, acc[1], 0, 0, 0);           \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+            if (P1 >= 0) issue_piece(P1 < 0 ? 0 : P1, t + 3, stn);                                                                \
+            if (P2 >= 0) issue_piece(P2 < 0 ? 0 : P2, t + 3, stn);                                                                \
+            RD;                                                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                                    \
+        } while (0)
+        MM(0, -1, -1, -1, reads(so, 2));
+        MM(1, -1, -1, -1, reads(so, 3));
+        VmWait<6>::go();                          // tile t+1 has landed (tiles t+2 may be in flight; tile t+3 is issued below)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        MM(2, 0, 1, 2, reads(so1, 0));
+        MM(3, 3, 4, 5, reads(so1, 1));
+#undef MM
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            C[(size_t)m * ldc + n] = acc[i][r];
+        }
+}
+
+int main()
+{
+    const int M = 512, N = 4096, K = 4096;
+    std::vector<bf16_t> hA((size_t)M * K), hB((size_t)N * K);
+    srand(1);
+    for (auto &v : hA) v = f2bf((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    for (auto &v : hB) v = f2bf(((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.05f);
+    bf16_t *A, *B; float *C, *R;
+    CK(hipMalloc(&A, hA.size() * 2)); CK(hipMalloc(&B, hB.size() * 2)); CK(hipMalloc(&C, (size_t)M * N * 4)); CK(hipMalloc(&R, (size_t)M * N * 4));
+    CK(hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_gemm, dim3(N / 256, M), dim3(256), 0, 0, A, B, R, M, N, K);
+    CK(hipDeviceSynchronize());
+    std::vector<float> hR((size_t)M * N), hC((size_t)M * N);
+    CK(hipMemcpy(hR.data(), R, hR.size() * 4, hipMemcpyDeviceToHost));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    std::vector<bf16_t> hBt((size_t)K * N);
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) hBt[(size_t)k * N + n] = hB[(size_t)n * K + k];
+    bf16_t *Bt; CK(hipMalloc(&Bt, hBt.size() * 2)); CK(hipMemcpy(Bt, hBt.data(), hBt.size() * 2, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int tm = M / 128, tn = N / 64;
+    struct V { const char *name; void (*go)(hipStream_t, const bf16_t *, const bf16_t *, float *, int, int); };
+    auto run = [&](const char *name, auto launch) {
+        CK(hipMemsetAsync(C, 0, (size_t)M * N * 4, st));
+        launch();
+        CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+        CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0, mx = 0;
+        for (size_t i = 0; i < hC.size(); ++i) { md = std::max(md, (double)fabsf(hC[i] - hR[i])); mx = std::max(mx, (double)fabsf(hR[i])); }
+        std::vector<float> ts;
+        for (int r = 0; r < 7; ++r) {
+            launch(); launch();
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < 20; ++i) launch();
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / 20 * 1000.f);
+        }
+        std::sort(ts.begin(), ts.end());
+        const double fl = 2.0 * M * N * K;
+        printf("%-52s med %7.2f us  %6.1f TF (%.3f of 2.5 PF)   max|diff| %.2e (max|ref| %.2e)\n", name, ts[3], fl / ts[3] * 1e-6, fl / ts[3] * 1e-6 / 2500.0, md, mx);
+    };
+    run("LDS-DMA 4-stage, DMA then reads then MFMAs", [&] { hipLaunchKernelGGL((gemm_dma<4, 0>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 4-stage, interleaved", [&] { hipLaunchKernelGGL((gemm_dma<4, 1>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("  ablation: no DMA in the loop (wrong result)", [&] { hipLaunchKernelGGL((gemm_dma<4, 1, 1>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("  ablation: no fragment reads (wrong result)", [&] { hipLaunchKernelGGL((gemm_dma<4, 1, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("  ablation: no DMA, no reads = MFMA + barrier", [&] { hipLaunchKernelGGL((gemm_dma<4, 1, 3>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("  ablation: no barrier (wrong result)", [&] { hipLaunchKernelGGL((gemm_dma<4, 1, 4>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 4-stage, 8 waves (k-split in the workgroup)", [&] { hipLaunchKernelGGL((gemm_dma8<4>), dim3(tm * tn), dim3(512), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 6-stage, 8 waves (k-split in the workgroup)", [&] { hipLaunchKernelGGL((gemm_dma8<6>), dim3(tm * tn), dim3(512), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("  8 waves, ablation: no DMA in the loop", [&] { hipLaunchKernelGGL((gemm_dma8<4, 1>), dim3(tm * tn), dim3(512), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 128-deep k-tiles, 3 stages, read-ahead 2", [&] { hipLaunchKernelGGL((gemm_dma128<3, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 128-deep k-tiles, 3 stages, read-ahead 3", [&] { hipLaunchKernelGGL((gemm_dma128<3, 3>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 128-deep k-tiles, 2 stages, read-ahead 2", [&] { hipLaunchKernelGGL((gemm_dma128<2, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 4-stage, B as [k][n] through ds_read_b64_tr_b16", [&] { hipLaunchKernelGGL((gemm_dma_bkn<4>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn); });
+    run("  [k][n] ablation: no DMA in the loop", [&] { hipLaunchKernelGGL((gemm_dma_bkn<4, 1>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn); });
+    run("  [k][n] ablation: plain b128 reads of the B tile", [&] { hipLaunchKernelGGL((gemm_dma_bkn<4, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn); });
+    run("v2 (asm reads, counted waits) [n][k], read-ahead 1", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 1>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("v2 (asm reads, counted waits) [n][k], read-ahead 2", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("v2 (asm reads, counted waits) [n][k], read-ahead 3", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 3>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("v2 (asm reads, counted waits) [k][n], read-ahead 1", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 1>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn); });
+    run("v2 (asm reads, counted waits) [k][n], read-ahead 2", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn); });
+    run("v2 (asm reads, counted waits) [k][n], read-ahead 3", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 3>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn); });
+    run("v3 (barrier mid-tile) [n][k]", [&] { hipLaunchKernelGGL((gemm_dma_v3<4, false>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("v3 (barrier mid-tile) [k][n]", [&] { hipLaunchKernelGGL((gemm_dma_v3<4, true>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn); });
+    {   // leading dimensions padded by 64 halfs (128 bytes): consecutive rows start in different L2 channels
+        const int LK = K + 64, LN = N + 64;
+        std::vector<bf16_t> pA((size_t)M * LK, 0), pB((size_t)N * LK, 0), pBt((size_t)K * LN, 0);
+        for (int m = 0; m < M; ++m) memcpy(&pA[(size_t)m * LK], &hA[(size_t)m * K], K * 2);
+        for (int n = 0; n < N; ++n) memcpy(&pB[(size_t)n * LK], &hB[(size_t)n * K], K * 2);
+        for (int k = 0; k < K; ++k) memcpy(&pBt[(size_t)k * LN], &hBt[(size_t)k * N], N * 2);
+        bf16_t *dA, *dB, *dBt; CK(hipMalloc(&dA, pA.size() * 2)); CK(hipMalloc(&dB, pB.size() * 2)); CK(hipMalloc(&dBt, pBt.size() * 2));
+        CK(hipMemcpy(dA, pA.data(), pA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, pB.data(), pB.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dBt, pBt.data(), pBt.size() * 2, hipMemcpyHostToDevice));
+        run("v2 [n][k] read-ahead 2, ld = K + 64", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, dA, dB, C, LK, LK, N, K, tm, tn); });
+        run("v2 [k][n] read-ahead 2, lda = K + 64, ldb = N + 64", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, dA, dBt, C, LK, LN, N, K, tm, tn); });
+        // cold weights: 8 different B matrices used round-robin (8 x 33.5 MB > the 256 MB Infinity Cache with A and C): every launch streams B from HBM
+        bf16_t *Bs[8], *Bps[8];
+        for (int i = 0; i < 8; ++i) { CK(hipMalloc(&Bs[i], hB.size() * 2)); CK(hipMemcpy(Bs[i], B, hB.size() * 2, hipMemcpyDeviceToDevice));
+                                      CK(hipMalloc(&Bps[i], pB.size() * 2)); CK(hipMemcpy(Bps[i], dB, pB.size() * 2, hipMemcpyDeviceToDevice)); }
+        int rr = 0;
+        run("v2 [n][k], B cold (8 copies round-robin), ld = K", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn); });
+        for (int extra : {64, 256, 512}) {
+            char nm[128]; snprintf(nm, sizeof nm, "v2 [n][k], B cold + %d workgroups prefetching the next B", extra);
+            run(nm, [&] { const int cur = rr++ & 7; hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn + extra), dim3(256), 0, st, A, Bs[cur], C, K, K, N, K, tm, tn,
+                                                                  (const uint4 *)Bs[(cur + 1) & 7], hB.size() * 2 / 16); });
+        }
+        run("  touch(B cold) alone, 2048 workgroups", [&] { hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, st, (const uint4 *)Bs[rr++ & 7], hB.size() * 2 / 16, C); });
+        run("  touch(B cold) then v2 [n][k] on the same B", [&] { const int cur = rr++ & 7; hipLaunchKernelGGL(touch, dim3(2048), dim3(256), 0, st, (const uint4 *)Bs[cur], hB.size() * 2 / 16, C);
+                                                             hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[cur], C, K, K, N, K, tm, tn); });
+        run("v2 [n][k], B cold, ring of 6", [&] { hipLaunchKernelGGL((gemm_dma_v2<6, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn); });
+        run("v2 [n][k], B cold, ring of 3", [&] { hipLaunchKernelGGL((gemm_dma_v2<3, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn); });
+        run("v2 [n][k], B cold, ring of 2", [&] { hipLaunchKernelGGL((gemm_dma_v2<2, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn); });
+        for (int st_ : {-16, -8, -4, -1}) { char nm[128]; snprintf(nm, sizeof nm, "v2 [n][k], B cold, k order rotated by %d tiles per m-tile", -st_);
+            run(nm, [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, st_); }); }
+        run("v2 [n][k], B warm, k order rotated by 16 tiles per m-tile", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, -16); });
+        bf16_t *Bts[8];
+        for (int i = 0; i < 8; ++i) { CK(hipMalloc(&Bts[i], hBt.size() * 2)); CK(hipMemcpy(Bts[i], Bt, hBt.size() * 2, hipMemcpyDeviceToDevice)); }
+        run("v2 [k][n], B cold", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn); });
+        run("v2 [k][n], B cold, k order rotated by 8 tiles per XCD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, 8); });
+        run("v2 [k][n], B cold, k order rotated by 3 tiles per XCD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, 3); });
+        run("v2 [n][k], B cold, k order rotated by 8 tiles per XCD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, 8); });
+        run("v2 [n][k], B cold (8 copies round-robin), ld = K + 64", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, dA, Bps[rr++ & 7], C, LK, LK, N, K, tm, tn); });
+    }
+    run("LDS-DMA 3-stage, interleaved", [&] { hipLaunchKernelGGL((gemm_dma<3, 1>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    run("LDS-DMA 6-stage, interleaved", [&] { hipLaunchKernelGGL((gemm_dma<6, 1>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
+    return 0;
+}
