@@ -119,6 +119,16 @@ int main(int argc, char **argv)
         hipLaunchKernelGGL((bp_gemm_dma<false, EPI_FWD_HIDDEN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
     vs.push_back({"dgrad glds 32x64x64 4-stage", [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
         hipLaunchKernelGGL((bp_gemm_dma<true, EPI_DGRAD>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
+    vs.push_back({"fwd  glds2 32x64x64 (asm reads, mid-tile barrier)", [&](hipStream_t s) { GemmArgs g; EpiArgs e; fwd_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
+        hipLaunchKernelGGL((bp_gemm_dma2<false, EPI_FWD_HIDDEN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
+    vs.push_back({"dgrad glds2 32x64x64 (asm reads, mid-tile barrier)", [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
+        hipLaunchKernelGGL((bp_gemm_dma2<true, EPI_DGRAD>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
+    vs.push_back({"dgrad glds2 ablation: no DMA in the loop", [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
+        hipLaunchKernelGGL((bp_gemm_dma2<true, EPI_DGRAD, 1>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
+    vs.push_back({"dgrad glds2 ablation: no barrier", [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
+        hipLaunchKernelGGL((bp_gemm_dma2<true, EPI_DGRAD, 2>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
+    vs.push_back({"dgrad glds2 ablation: no DMA, no barrier", [&](hipStream_t s) { GemmArgs g; EpiArgs e; dg_args(g, e); g.tiles_m = B / 32; g.tiles_n = H / 64;
+        hipLaunchKernelGGL((bp_gemm_dma2<true, EPI_DGRAD, 3>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g, e); }, fl});
     // short-kernel MFMA shapes: G workgroups x 4 waves x N MFMAs per wave, NACC chains (what a 64x64x256 wgrad tile issues: 128 per wave)
 #define SHAPE(G, N, NACC) vs.push_back({"mfma shape G" #G " n" #N " chains" #NACC, [&](hipStream_t s) { hipLaunchKernelGGL(mfma_peak<NACC>, dim3(G), dim3(256), 0, s, Yo, N / NACC); }, (double)G * 4 * N * 4096.0})
     SHAPE(1024, 128, 2); SHAPE(768, 128, 2); SHAPE(256, 128, 2); SHAPE(1024, 128, 4); SHAPE(1024, 128, 1); SHAPE(256, 512, 2); SHAPE(3648, 128, 2); SHAPE(2048, 128, 2);
@@ -165,6 +175,26 @@ int main(int argc, char **argv)
             double md = 0, mx = 0; size_t nz = 0;
             for (size_t i = 0; i < nY; ++i) { md = std::max(md, (double)fabsf(r1[i] - r2[i])); mx = std::max(mx, (double)fabsf(r1[i])); nz += r2[i] != 0.f; }
             printf("CHECK2 %s glds vs product: max|diff| %.3e, max|ref| %.3e, nonzero outputs %zu of %zu\n", kind ? "dgrad" : "fwd", md, mx, nz, nY);
+        }
+    }
+    if (getenv("PROBE_CHECK3")) {
+        const size_t nY = (size_t)B * LD;
+        std::vector<float> r1(nY), r2(nY);
+        for (int kind = 0; kind < 2; ++kind) {
+            for (int which = 0; which < 2; ++which) {
+                CK(hipMemset(Yo, 0, nY * 4));
+                GemmArgs g; EpiArgs e;
+                if (kind == 0) { fwd_args(g, e); e.drop_thresh = 0; } else dg_args(g, e);
+                if (which == 0) { if (kind == 0) go<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>(st, g, e, B, H, 0); else go<32, 64, 64, 1, 2, true, true, EPI_DGRAD, 1>(st, g, e, B, H, 0); }
+                else { g.tiles_m = B / 32; g.tiles_n = H / 64;
+                       if (kind == 0) hipLaunchKernelGGL((bp_gemm_dma2<false, EPI_FWD_HIDDEN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, st, g, e);
+                       else hipLaunchKernelGGL((bp_gemm_dma2<true, EPI_DGRAD>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, st, g, e); }
+                CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+                CK(hipMemcpy(which ? r2.data() : r1.data(), Yo, nY * 4, hipMemcpyDeviceToHost));
+            }
+            double md = 0, mx = 0; size_t nz = 0;
+            for (size_t i = 0; i < nY; ++i) { md = std::max(md, (double)fabsf(r1[i] - r2[i])); mx = std::max(mx, (double)fabsf(r1[i])); nz += r2[i] != 0.f; }
+            printf("CHECK3 %s glds2 vs product: max|diff| %.3e, max|ref| %.3e, nonzero outputs %zu of %zu\n", kind ? "dgrad" : "fwd", md, mx, nz, nY);
         }
     }
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
