@@ -1,13 +1,11 @@
 #!/bin/bash
-# A/B of the merged dgrad+wgrad launches (BP_MERGE) on the C2 fp32 step, plus the parity tests under the switch
+# A/B of a development switch on the C2 fp32 step (alternating, same box)
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out/merge
-for rep in 1 2; do
-  for m in 0 1 2; do
-    echo "BP_MERGE=$m" >> gpurun_out/merge/ab.txt
-    BP_MERGE=$m timeout 300 python tools/bench_bf16.py c2f32 >> gpurun_out/merge/ab.txt 2>&1
+mkdir -p gpurun_out/ab; rm -f gpurun_out/ab/ab.txt
+for rep in 1 2 3; do
+  for m in 0 1; do
+    if [ $m = 1 ]; then export ${SW:-BP_WG5}=1; else unset ${SW:-BP_WG5}; fi
+    echo "${SW:-BP_WG5}=$m $(timeout 300 python tools/bench_bf16.py c2f32 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')" >> gpurun_out/ab/ab.txt
   done
 done
-BP_MERGE=1 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_autograd.py -m gpu -x -q > gpurun_out/merge/pytest.log 2>&1
-echo "pytest rc=$?" >> gpurun_out/merge/ab.txt
-cat gpurun_out/merge/ab.txt
+cat gpurun_out/ab/ab.txt
