@@ -694,7 +694,10 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
         }
         a.first_tile[cnt] = t; a.n = cnt;
 #define BF_DMA_LAUNCH(K)                                                                                             \
-        do { if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, false>), dim3(t), dim3(256), 0, h->stream, a);        \
+        do { static const bool four = getenv("BP_BF16_WGRAD_FOUR_WAVES") != nullptr;   /* development A/B switch */     \
+             /* fused update: six waves (two of them own W / delta), 64-frame k-tiles in a ring of 3 when the bunch has at least 4 */ \
+             if (fused && !four) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(t), dim3(384), 0, h->stream, a); \
+             else if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, false>), dim3(t), dim3(256), 0, h->stream, a);    \
              else hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, true>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
         switch (h->Bp) {
         case 128: BF_DMA_LAUNCH(128); break;
