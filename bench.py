@@ -189,7 +189,7 @@ def c5_line(dnnse_amd, dev, steps=40):
         for k, v in pm["kernels"].items():
             if k.startswith(("void bp_gemm_bf16", "void bp_wgrad_dma_bf16", "bp_bias_bf16", "bp_to_bf16_both")) and "fetch_MB_corrected_x2" in v and "write_MB" in v:
                 tot += (v["fetch_MB_corrected_x2"] + v["write_MB"]) * 1e6 * v["launches"]
-                if k.startswith("void bp_wgrad_dma_bf16") and "false" in k:
+                if k.startswith("void bp_wgrad_dma_bf16") and ("false" in k or "_six" in k):
                     steps_prof = v["launches"]                     # ONE grouped wgrad launch per step
         if steps_prof:
             note = pm.get("note", "")

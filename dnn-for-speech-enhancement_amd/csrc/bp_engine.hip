@@ -578,10 +578,14 @@ static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int 
         static const bool no_dma = getenv("BP_BF16_GEMM_NO_DMA") != nullptr;      // development A/B switch
         if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_DGRAD) {              // LDS-DMA staged loop (bp_bf16.h)
             if (!no_dma && (g.tiles_n & 7) == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && e.ldc % 8 == 0 && e.ldct % 8 == 0 && e.n_limit == N) {
-                // k-tile offset between the m-tiles that share a weight panel (measured in the step, configs[4]: forward -- weights
-                // cold behind the update launch -- 38.1 us in phase, 33.7 a quarter of K apart; dgrad -- weights read by the forward
-                // 0.3 ms earlier -- 31.4 in phase, 30.4 two tiles apart, 32.3 a quarter apart)
-                g.k_rot = EPI == BEPI_FWD_HIDDEN ? (g.K / 64) / g.tiles_m : 2;
+                // k-tile offset between the m-tiles that share a weight panel (bp_bf16.h).  Measured in the step, configs[4], us per
+                // launch: forward (weights cold behind the update launch) 38.1 in phase, 36.3 four tiles apart, 33.7 a quarter of K
+                // apart; dgrad (weights read by the forward 0.3 ms earlier) 31.4 in phase, 30.4 two tiles apart, 32.3 a quarter apart.
+                // A quarter of K apart the four sharers no longer meet in L2 and the forward fetches its panel FOUR times (164 MB
+                // instead of 68 MB per launch at the L2's memory side, profiles/r04_bf16_gemm_probe.txt): 2.6 us per launch are not
+                // worth 2.4x the fabric traffic, so both stay within reach of each other's lines.  BP_BF16_ROT_FWD overrides (A/B).
+                static const int rot_fwd = getenv("BP_BF16_ROT_FWD") ? atoi(getenv("BP_BF16_ROT_FWD")) : 4;
+                g.k_rot = EPI == BEPI_FWD_HIDDEN ? rot_fwd : 2;
                 hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128, BKN, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
                 return hipGetLastError();
             }
