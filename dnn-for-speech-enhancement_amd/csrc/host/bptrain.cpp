@@ -351,8 +351,13 @@ int main(int argc, char **argv)
         if (ring_pinned) bp_host_unregister(ring->base());
     } else {
         ChunkStream chunks(reader, tp, chunk_index, true, P.prefetch, P.stack_on_device);
+        const bool chunk_times = getenv("BPTRAIN_CHUNK_TIMES") != nullptr;
         for (int i = 0; i < nchunks; ++i) {
             const WindowChunk &w = chunks.get(i);           // (the read of chunk i+1 is now running behind us)
+            if (chunk_times) {                              // development aid: when each chunk was handed over (the host blocks on the
+                struct timespec tc; clock_gettime(CLOCK_MONOTONIC, &tc);   // device two chunks back, so the intervals are device time per chunk)
+                fprintf(stderr, "chunk %d at %.4f s\n", i + 1, (tc.tv_sec - ts0.tv_sec) + 1e-9 * (tc.tv_nsec - ts0.tv_nsec));
+            }
             fprintf(log, "Starting chunk %d of %d containing %d samples.\n", i + 1, nchunks, w.n_samples);
             fflush(log);
             if (P.stack_on_device) {
