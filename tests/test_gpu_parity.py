@@ -484,6 +484,7 @@ BF_CASES = [
     ([257, 320, 192, 129], 96, 2, 0, 0, 0.0, True),               # dropout, ragged bunch
     ([300, 1024, 1024, 257], 256, 2, 0, 0, 0.0, True),            # several k-tiles and workgroups per GEMM
     ([70, 130, 64, 20], 128, 2, 1, 1, 0.001, True),               # LDS-DMA wgrad (bunch 128): odd widths, Sigmoid, classic, weight cost
+    ([200, 2048, 2048, 40], 1024, 1, 0, 0, 0.0, True),            # bunch 1024: six-wave update launch with 16 k-tiles; LDS-DMA staged GEMMs with 8 m-tiles x 32 n-tiles, K = 2048
 ]
 
 
