@@ -1,17 +1,17 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out/bfdma; rm -rf $O; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_autograd.py tests/test_dp_native.py tests/test_bptrain.py tests/test_bpforward.py -m gpu -x -q -k "bf16 or config5 or compute_dtype" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_autograd.py tests/test_dp_native.py tests/test_bptrain.py tests/test_bpforward.py -m gpu -x -q -k "bf16 or config5 or compute_dtype" > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest.log
 cd /tmp; export TMPDIR=/tmp
-for m in six four six four; do
-  unset BP_BF16_WGRAD_FOUR_WAVES; [ $m = four ] && export BP_BF16_WGRAD_FOUR_WAVES=1
+for m in split nosplit split nosplit; do
+  unset BP_BF16_NO_OUT_SPLIT; [ $m = nosplit ] && export BP_BF16_NO_OUT_SPLIT=1
   d=$O/kt$m
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -o kt -- python $R/tools/bench_bf16.py c5bf16 > $d.log 2>&1
-  echo "== wgrad $m waves"; grep -o '"ms_per_step": [0-9.]*' $d.log
+  echo "== output layer $m"; grep -o '"ms_per_step": [0-9.]*' $d.log
   python - $d/kt_kernel_stats.csv <<'P'
 import csv,sys
 for r in csv.reader(open(sys.argv[1])):
-    if 'wgrad' in r[0]: print('  ', r[0][:66].ljust(68), r[1], r[3][:8])
+    if 'bf16<1' in r[0] or 'bf16<5' in r[0] or 'out_reduce' in r[0]: print('  ', r[0][:66].ljust(68), r[1], r[3][:8])
 P
 done
 find $O -name '*kernel_trace.csv' -delete; find $O -name '*.db' -delete
