@@ -610,6 +610,102 @@ __global__ __launch_bounds__(256) void gemm_dma_v3(const bf16_t *A, const bf16_t
         }
 }
 
+// Version 4: SEPARATE rings for the two operands.  Cold weights are bound by the unique bytes in flight (4 sharers request the same
+// B lines: 192 KB per XCD against ~2.5 us of HBM latency), and s_waitcnt vmcnt retires in order, so B can only run further ahead than
+// A if OTHER waves issue it: wave 3 issues all 8 B pieces of tile t+DB, waves 0-2 the 16 A pieces of tile t+DA (6 / 5 / 5).
+template <bool BKN, int STA, int STB>
+__global__ __launch_bounds__(256) void gemm_dma_v4(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n, int stag = 0)
+{
+    constexpr int ASTAGE = 128 * 128, BSTAGE = 64 * 128, DA = STA - 1, DB = STB - 1;
+    constexpr int NRD = BKN ? 4 : 3;
+    __shared__ __attribute__((aligned(1024))) char smem[STA * ASTAGE + STB * BSTAGE];
+    char *sa = smem, *sb = smem + STA * ASTAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    const int nt = K / 64;
+    const int rot = (tile_m * stag) % nt;
+    // piece p of the A tile = rows 8p..8p+7 (16 pieces); of the B tile 8 pieces.  wave 0: A 0-5, wave 1: A 6-10, wave 2: A 11-15, wave 3: B 0-7
+    const int first = wave == 0 ? 0 : wave == 1 ? 6 : wave == 2 ? 11 : 0, cnt = wave == 0 ? 6 : wave == 3 ? 8 : 5;
+    const bf16_t *src[8]; size_t step[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int p = first + (i < cnt ? i : 0), r = 8 * p + (lane >> 3);
+        if (wave != 3) { const int c = (lane & 7) ^ ((r >> 1) & 7); src[i] = A + (size_t)(m0 + r) * lda + c * 8; step[i] = 64; }
+        else if (!BKN) { const int rr = 128 + r, c = (lane & 7) ^ ((rr >> 1) & 7); src[i] = B + (size_t)(n0 + r) * ldb + c * 8; step[i] = 64; }
+        else { const int c = (lane & 7) ^ (4 * ((r >> 1) & 1)); src[i] = B + (size_t)r * ldb + n0 + c * 8; step[i] = (size_t)64 * ldb; }
+    }
+    auto issue_piece = [&](int i, int t) {          // piece slot i of this wave, tile t
+        int tt = t < nt ? t : nt - 1;
+        tt += rot; if (tt >= nt) tt -= nt;
+        char *dst = wave != 3 ? sa + (t % STA) * ASTAGE + (first + i) * 1024 : sb + (t % STB) * BSTAGE + i * 1024;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * step[i]), (lds_ptr)dst, 16, 0, 0);
+    };
+    const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 32 + (lane & 31), h = lane >> 5;
+    const int sa_ = (ra >> 1) & 7, sb_ = (rb >> 1) & 7;
+    const unsigned ldsa = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)sa, ldsb = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)sb;
+    unsigned aq[4], bq[4];
+    const int j = (lane & 15) >> 2, cb = 4 * wn + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        aq[q] = ldsa + ra * 128 + 16 * (h ^ (sa_ & 1)) + 32 * (q ^ (sa_ >> 1));
+        bq[q] = BKN ? ldsb + (16 * q + 8 * h + j) * 128 + 16 * (cb ^ (4 * ((j >> 1) & 1))) + 8 * (lane & 1)
+                    : ldsb + (rb - 128) * 128 + 16 * (h ^ (sb_ & 1)) + 32 * (q ^ (sb_ >> 1));
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    if (wave != 3) { for (int t = 0; t < DA; ++t) for (int i = 0; i < cnt; ++i) issue_piece(i, t); }
+    else { for (int t = 0; t < DB; ++t) for (int i = 0; i < 8; ++i) issue_piece(i, t); }
+    f32x4v a0[4], a1[4], bb[4]; v4s blo[4], bhi[4];
+    auto reads = [&](unsigned soa, unsigned sob, int q) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a0[q]) : "v"(aq[q] + soa));
+        if constexpr (BKN) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(blo[q]) : "v"(bq[q] + sob));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(bhi[q]) : "v"(bq[q] + sob));
+        } else asm volatile("ds_read_b128 %0, %1" : "=v"(bb[q]) : "v"(bq[q] + sob));
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[q]) : "v"(aq[q] + soa));
+    };
+    auto bfrag = [&](int q) {
+        if constexpr (BKN) return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(blo[q], bhi[q], 0, 1, 2, 3, 4, 5, 6, 7));
+        else return __builtin_bit_cast(bf16x8_t, bb[q]);
+    };
+    for (int t = 0; t < nt; ++t) {
+        const unsigned soa = (unsigned)((t % STA) * ASTAGE), sob = (unsigned)((t % STB) * BSTAGE);
+        // this wave's pieces of tile t have landed: behind them it has issued (DA-1) or (DB-1) more tiles of its own
+        if (wave == 0) VmWait<(DA - 1) * 6>::go(); else if (wave == 3) VmWait<(DB - 1) * 8>::go(); else VmWait<(DA - 1) * 5>::go();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        reads(soa, sob, 0); reads(soa, sob, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int tn_ = wave != 3 ? t + DA : t + DB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3) ARRIVED(q, NRD); else ARRIVED(q, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8_t bf = bfrag(q);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a0[q]), bf, acc[0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * q < cnt) issue_piece(2 * q, tn_);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a1[q]), bf, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * q + 1 < cnt) issue_piece(2 * q + 1, tn_);
+            if (q + 2 < 4) reads(soa, sob, q + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int n = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            C[(size_t)m * ldc + n] = acc[i][r];
+        }
+}
+
 int main()
 {
     const int M = 512, N = 4096, K = 4096;
@@ -703,6 +799,21 @@ int main()
         for (int st_ : {-16, -8, -4, -1}) { char nm[128]; snprintf(nm, sizeof nm, "v2 [n][k], B cold, k order rotated by %d tiles per m-tile", -st_);
             run(nm, [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, st_); }); }
         run("v2 [n][k], B warm, k order rotated by 16 tiles per m-tile", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, -16); });
+        for (int pad : {256, 1024, 2048 + 64, 4096 + 64}) {   // cold B with other row strides: is the 8 KB stride (HBM channel / bank mapping) what makes cold slow?
+            const int LB = K + pad;
+            std::vector<bf16_t> q((size_t)N * LB, 0);
+            for (int n = 0; n < N; ++n) memcpy(&q[(size_t)n * LB], &hB[(size_t)n * K], K * 2);
+            bf16_t *Bq[8];
+            for (int i = 0; i < 8; ++i) { CK(hipMalloc(&Bq[i], q.size() * 2)); CK(hipMemcpy(Bq[i], q.data(), q.size() * 2, hipMemcpyHostToDevice)); }
+            char nm[128]; snprintf(nm, sizeof nm, "v2 [n][k], B cold, ldb = K + %d", pad);
+            run(nm, [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bq[rr++ & 7], C, K, LB, N, K, tm, tn); });
+            for (int i = 0; i < 8; ++i) CK(hipFree(Bq[i]));
+        }
+        run("v4 (separate rings A4 / B8) [n][k], B warm", [&] { hipLaunchKernelGGL((gemm_dma_v4<false, 4, 8>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, 0); });
+        run("v4 (separate rings A4 / B8) [n][k], B cold", [&] { hipLaunchKernelGGL((gemm_dma_v4<false, 4, 8>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 0); });
+        run("v4 (separate rings A4 / B8) [n][k], B cold, sharers 2 tiles apart", [&] { hipLaunchKernelGGL((gemm_dma_v4<false, 4, 8>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 2); });
+        run("v4 (separate rings A3 / B12) [n][k], B cold", [&] { hipLaunchKernelGGL((gemm_dma_v4<false, 3, 12>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 0); });
+        run("v4 (separate rings A4 / B4) [n][k], B cold", [&] { hipLaunchKernelGGL((gemm_dma_v4<false, 4, 4>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 0); });
         bf16_t *Bts[8];
         for (int i = 0; i < 8; ++i) { CK(hipMalloc(&Bts[i], hBt.size() * 2)); CK(hipMemcpy(Bts[i], Bt, hBt.size() * 2, hipMemcpyDeviceToDevice)); }
         run("v2 [k][n], B cold", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn); });
