@@ -14,7 +14,9 @@
 // chunk per lane, 32 rows per half-wave) then touches all 64 banks once per 16-lane group.  64x64 tiles, 4 waves of
 // one 32x32 block, 32-frame k-tiles in a 4-stage ring (32 KB => 4 workgroups per CU), three tiles in flight, ONE raw
 // s_barrier per k-tile with an exact counted vmcnt; the W / delta tile is fetched by plain loads issued right behind
-// the LAST operand tile.  The step is HBM-bound here (20 bytes per parameter: fp32 W and delta read + written, one bf16
+// the LAST operand tile (four-wave form: WgradDmaBf::run, the data-parallel gradient store and the A/B fallback).  The fused update
+// of the single-device step is the SIX-wave form at the end of this file (WgradDmaBf6: two waves own W / delta on their own
+// vmcnt; 64-frame k-tiles in a ring of 3 for bunches of 256 frames and more).  The step is HBM-bound here (20 bytes per parameter: fp32 W and delta read + written, one bf16
 // shadow written); what this kernel buys over bp_gemm_bf16<BEPI_WGRAD_UPDATE> is occupancy (80 VGPRs), no register
 // staging, one launch for all layers instead of one GEMM + one bias kernel per layer.
 #pragma once
