@@ -15,8 +15,9 @@
 // lines) and the MFMA fragments -- 8 consecutive k of one column per lane -- come out of it through the hardware
 // transpose read ds_read_b64_tr_b16 (two per fragment).  Round 3 kept a second, transposed shadow instead, which the
 // HBM-bound weight-gradient launch had to write: 2 bytes per parameter and step (160 MB at configs[4]).
-// One kernel (128/64/32 x 64 x 64 tiles, 4 waves, ds_read_b128 fragment reads from padded LDS rows) serves all three
-// GEMMs with different epilogues.
+// One kernel template (128/64/32 x 64 x 64 tiles, 4 waves) serves forward, dgrad and the per-layer wgrad fallback with different
+// epilogues, in two staging forms: register-staged (global -> VGPR -> ds_write_b128 into padded LDS rows; every shape) and LDS-DMA
+// (DMA = true; the 128-row tiles of the 4096-wide layers of configs[4]).  The grouped update launch is bp_wgrad_dma_bf16.h.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
