@@ -706,6 +706,97 @@ __global__ __launch_bounds__(256) void gemm_dma_v4(const bf16_t *A, const bf16_t
         }
 }
 
+// Version 5: 128 x 128 tiles (wave tile 64 x 64: every fragment feeds two MFMAs -> 1 LDS read per MFMA instead of 1.5), K split over
+// TWO workgroups per tile (grid = 128 tiles x 2 halves = 256 workgroups).  This probe variant stores the two fp32 partial tiles
+// side by side (C and C + slab): the host adds them -- an upper bound for a kernel that also has to exchange them.
+template <int ST>
+__global__ __launch_bounds__(256) void gemm_dma_v5(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n, size_t slab)
+{
+    constexpr int STAGE = 256 * 128, D = ST - 1, NRD = 4;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    // block b -> XCD b & 7; inside an XCD: both k-halves of (tiles_n / 8) n-tiles x all m-tiles
+    const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, kh = jj & 1, tl = jj >> 1, per = tiles_n >> 3;
+    const int tile_n = xcd * per + tl / tiles_m, tile_m = tl % tiles_m;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int kbase = kh * (K / 2), nt = K / 2 / 64;
+    const bf16_t *src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 8 * (wave * 8 + i) + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+        src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + kbase + c * 8;
+    }
+    auto issue_piece = [&](int i, int t, int st) {
+        const int tt = t < nt ? t : nt - 1;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * 64), (lds_ptr)(smem + st * STAGE + (wave * 8 + i) * 1024), 16, 0, 0);
+    };
+    const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 64 + (lane & 31), h = lane >> 5;
+    const int sa = (ra >> 1) & 7, sb = (rb >> 1) & 7;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)smem;
+    unsigned aq[4], bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        aq[q] = lds0 + ra * 128 + 16 * (h ^ (sa & 1)) + 32 * (q ^ (sa >> 1));
+        bq[q] = lds0 + rb * 128 + 16 * (h ^ (sb & 1)) + 32 * (q ^ (sb >> 1));
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f; }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_piece(i, t, t);
+    f32x4v a0[4], a1[4], b0[4], b1[4];
+#define V5_READS(so, q) do { asm volatile("ds_read_b128 %0, %1" : "=v"(a0[q]) : "v"(aq[q] + (so)));                 \
+                             asm volatile("ds_read_b128 %0, %1" : "=v"(b0[q]) : "v"(bq[q] + (so)));                 \
+                             asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(a1[q]) : "v"(aq[q] + (so)));     \
+                             asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(b1[q]) : "v"(bq[q] + (so))); } while (0)
+    for (int t = 0; t < nt; ++t) {
+        const unsigned so = (unsigned)((t % ST) * STAGE);
+        const int stn = (t + D) % ST;
+        VmWait<(D - 1) * 8>::go();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        V5_READS(so, 0); V5_READS(so, 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a0[q]), "+v"(a1[q]), "+v"(b0[q]), "+v"(b1[q]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[q]), "+v"(a1[q]), "+v"(b0[q]), "+v"(b1[q]));
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8_t fa0 = __builtin_bit_cast(bf16x8_t, a0[q]), fa1 = __builtin_bit_cast(bf16x8_t, a1[q]);
+            const bf16x8_t fb0 = __builtin_bit_cast(bf16x8_t, b0[q]), fb1 = __builtin_bit_cast(bf16x8_t, b1[q]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(2 * q, t + D, stn);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(2 * q + 1, t + D, stn);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < 4) V5_READS(so, q + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef V5_READS
+    float *out = C + (size_t)kh * slab;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(size_t)m * ldc + n] = acc[i][j][r];
+            }
+        }
+}
+
 int main()
 {
     const int M = 512, N = 4096, K = 4096;
@@ -821,6 +912,31 @@ int main()
         run("v2 [k][n], B cold, k order rotated by 3 tiles per XCD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, 3); });
         run("v2 [n][k], B cold, k order rotated by 8 tiles per XCD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, (const uint4 *)nullptr, (size_t)0, 8); });
         run("v2 [n][k], B cold (8 copies round-robin), ld = K + 64", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, dA, Bps[rr++ & 7], C, LK, LK, N, K, tm, tn); });
+    }
+    {
+        float *C2; CK(hipMalloc(&C2, (size_t)2 * M * N * 4));
+        std::vector<float> h2((size_t)2 * M * N);
+        auto run5 = [&](const char *name, auto launch) {
+            CK(hipMemsetAsync(C2, 0, (size_t)2 * M * N * 4, st));
+            launch();
+            CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+            CK(hipMemcpy(h2.data(), C2, h2.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0;
+            for (size_t i = 0; i < (size_t)M * N; ++i) md = std::max(md, (double)fabsf(h2[i] + h2[(size_t)M * N + i] - hR[i]));
+            std::vector<float> ts;
+            for (int r = 0; r < 7; ++r) {
+                launch(); launch();
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 20; ++i) launch();
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / 20 * 1000.f);
+            }
+            std::sort(ts.begin(), ts.end());
+            const double fl = 2.0 * M * N * K;
+            printf("%-52s med %7.2f us  %6.1f TF (%.3f of 2.5 PF)   max|sum of partials - ref| %.2e\n", name, ts[3], fl / ts[3] * 1e-6, fl / ts[3] * 1e-6 / 2500.0, md);
+        };
+        run5("v5 128x128 tiles, K split over 2 workgroups, ring 4", [&] { hipLaunchKernelGGL((gemm_dma_v5<4>), dim3(256), dim3(256), 0, st, A, B, C2, K, K, N, K, M / 128, N / 128, (size_t)M * N); });
+        run5("v5 128x128 tiles, K split over 2 workgroups, ring 3", [&] { hipLaunchKernelGGL((gemm_dma_v5<3>), dim3(256), dim3(256), 0, st, A, B, C2, K, K, N, K, M / 128, N / 128, (size_t)M * N); });
     }
     run("LDS-DMA 3-stage, interleaved", [&] { hipLaunchKernelGGL((gemm_dma<3, 1>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
     run("LDS-DMA 6-stage, interleaved", [&] { hipLaunchKernelGGL((gemm_dma<6, 1>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn); });
