@@ -13,9 +13,11 @@
 // no host synchronisation and no collective library on the data path.  The reference moved the same
 // data through GPU 0 with cublasSaxpy / cublasScopy over P2P (BP_GPU.cu:863-904).
 //
-// Memory-model contract (gfx950; LLVM AMDGPU memory model).  No per-workgroup fences: a system-scope release or
-// acquire (buffer_wbl2 / buffer_inv sc0 sc1) acts on the whole L2 of the executing XCD, and one per workgroup made
-// the exchange kernel 5x slower and evicted the L2 under the GEMMs that run beside it (rocprofv3, round 2).  Instead
+// Memory-model contract (gfx950; LLVM AMDGPU memory model).  No per-workgroup ACQUIRE and no fence in the exchange kernel:
+// a system-scope acquire (buffer_inv sc0 sc1) drops the whole L2 of the executing XCD, and a release + acquire per
+// workgroup made the exchange kernel 5x slower and evicted the L2 under the GEMMs that run beside it (rocprofv3, round 2).
+// The one release on the data path is the gradient store's per-tile count (bp_wgrad_dma.h: system-scope release
+// fetch_add behind the workgroup's barrier, i.e. one L2 write-back request per 64x64 tile).  Otherwise
 //   * the gradient buffer is FINE-GRAINED device memory (never cached dirty; peers' mappings of it are uncached)
 //     and is read with system-scope (sc0 sc1) 16-byte loads, so a reader can neither see a stale L2 line nor leave one;
 //   * new weights are written with system-scope WRITE-THROUGH (sc0 sc1) 16-byte stores into the (cacheable) parameter
@@ -222,7 +224,7 @@ __global__ void bp_dp_copy(float *dst, const float *src, unsigned long long n4)
 // what this rank's next kernels read with plain cached loads once its flag has risen; (G) gradients this rank's kernels
 // wrote with plain stores into fine-grained memory are what a peer's system-scope loads return once ITS flag has risen.
 // bp_dp_attach checks both on the actual devices of the group, with the product's own access flavours and ordering
-// recipe, on probe buffers of the same allocation kinds, before any training step relies on them (bp_engine.hip,
+// recipe, on probe buffers of the same allocation kinds, before any training step relies on them (bp_dp.hip,
 // dp_selftest).  If (W) fails as is, the group falls back to an explicit system-scope acquire on every XCD behind each
 // wait (bp_dp_l2_invalidate); if it still fails, bp_dp_attach fails.
 #define BP_DP_PROBE_FLOATS (64 * 1024)            /* 256 KB per probe buffer */
@@ -272,14 +274,14 @@ __global__ void bp_dp_probe_fill(float *probe, unsigned round, unsigned rank)
         probe[i] = bp_probe_value(round, rank, i);
 }
 // the same fill with the product's IN-KERNEL hand-off (bp_wgrad_dma.h, EpiArgs::done): plain stores, every wave drains, one
-// lane per workgroup counts -- no kernel boundary between these stores and the readers
+// lane per workgroup counts with a system-scope release -- no kernel boundary between these stores and the readers
 __global__ __launch_bounds__(256) void bp_dp_probe_fill_count(float *probe, unsigned round, unsigned rank, unsigned *done)
 {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < BP_DP_PROBE_FLOATS; i += gridDim.x * blockDim.x)
         probe[i] = bp_probe_value(round, rank, i);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // reader: system-scope 16-byte loads of slice `rank` of every rank's fine-grained probe (the reduce-scatter read)
 __global__ void bp_dp_probe_check_remote(DpReduceArgs a, unsigned round, unsigned *bad)

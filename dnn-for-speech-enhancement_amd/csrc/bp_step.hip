@@ -1,13 +1,6 @@
-// bp_engine.hip -- C-ABI implementation (include/bp_c_api.h): device state of one BP_GPU
-// replacement object and the per-bunch launch sequence.  gfx950 only.
-//
-// Device layout (all fp32): every layer width s_l is padded to ld_l = roundup(s_l, 64); pad
-// columns/rows are zero and stay zero under the step (DESIGN.md "padding invariants"), so the
-// GEMM tiles never need column predicates and every row is 256-byte aligned.
-//   W_l   [ld_{l-1}][ld_l]   (reference layout weights[l][p*cur+c], BP_GPU.cu:139)
-//   y_l   [B][ld_l]          post-activation, post-dropout output of layer l (layer_y)
-//   dx_l  [B][ld_l]          dE/dx of layer l (layer_dedx); layer_x/dydx/dedy are never stored
-//   in    [cap][ld_0], targ [cap][ld_{L-1}]   resident chunk (dev.in/dev.targ, BP_GPU.cu:127-130)
+// bp_step.hip -- C-ABI implementation (include/bp_c_api.h), part 1 of 3: the device state of one BP_GPU replacement
+// object, the chunk interface and the per-bunch launch sequence (training, CV, forward).  gfx950 only.  The handle and
+// what the other two translation units use of this one: bp_handle.h.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,95 +10,15 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/bp_c_api.h"
+#include "bp_handle.h"
 #include "bp_kernels.h"
 #include "bp_bf16.h"
-#include "bp_dp.h"
-#include "bp_rdv.h"
 #include "bp_wgrad_dma.h"
 #include "bp_wgrad_dma_bf16.h"
 
-#include <dlfcn.h>
+thread_local std::string g_bp_err;
 
-struct ncclUniqueIdBytes { char internal[128]; };   // = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value
-
-static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) { g_err = msg; return code; }
-#define HIPCHK(x)                                                                                     \
-    do {                                                                                              \
-        hipError_t _e = (x);                                                                          \
-        if (_e != hipSuccess)                                                                         \
-            return fail(BP_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(_e));               \
-    } while (0)
-
-static inline int pad64(int x) { return (x + 63) & ~63; }
-
-struct bp_handle {
-    bp_config cfg;
-    int L;                       // number of layer sizes
-    int s[BP_MAXLAYER], ld[BP_MAXLAYER];
-    int B, Bg;                   // local / global bunch
-    int cap, chunk_frames;
-    hipStream_t own_stream, stream;
-    bool grouped;                // all wide wgrad+update problems of a step in one grouped launch
-    // parameters and momentum state live in two flat arenas with the layout of the flat gradient buffer
-    // ([W_1|b_1|W_2|b_2|...], padded; g_off/g_cnt) so that data-parallel ranks can export them as ONE hipIpc
-    // allocation each and the sharded update is a flat elementwise pass (bp_dp.h); W/b/dW/db point into them
-    float *params, *deltas;
-    float *W[BP_MAXLAYER], *b[BP_MAXLAYER], *dW[BP_MAXLAYER], *db[BP_MAXLAYER];
-    struct bp_dp *dp;            // attached data-parallel group (bp_dp_attach) or null
-    struct StepProf *prof;       // bp_profile_step in progress: an event after every launch of the step
-    const uint8_t *inj_mask[BP_MAXLAYER];   // bp_train_resident_masked in progress: device masks of this bunch per layer output
-    const float *inj_x0;                    // ... and the masked copy of its input rows
-    float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
-    float *in, *in_drop, *targ, *out_dev;
-    float *slabs; size_t slab_stride; int out_splits;   // split-K workspace of the output layer
-    float *grad; size_t grad_floats; size_t g_off[BP_MAXLAYER], g_cnt[BP_MAXLAYER];
-    float *host_out;             // pinned staging for CV outputs (grow-only, whole chunk)
-    float *out_chunk;            // device: network outputs of a whole chunk [frames][ld_L] (CV / forward), grow-only
-    size_t out_chunk_frames;
-    uint32_t step;               // bunches trained so far (dropout stream position)
-    long mask_lo, mask_hi; uint32_t mask_step0;
-    uint32_t th_vis, th_hid;
-    hipEvent_t ev0, ev1; float last_ms; int last_bunches;
-    std::vector<void *> allocs;
-    // Upload path: host->device copies run on copy_stream so that chunk i+1 is uploaded while chunk i trains.
-    // STACKED chunks (bp_upload_chunk: the caller hands [frames][layersizes[0]] rows, the reference's interface) alternate
-    // between two device buffer pairs (in/targ and in_alt/targ_alt; allocated on first use).
-    // WINDOW chunks (bp_upload_chunk_windows: raw frames + index tables) stay as they are uploaded -- two
-    // grow-only staging sets alternate the same way -- and every bunch stacks ITS rows into the tile x0s/tgs right
-    // before its forward (bp_stage_bunch): no stacked chunk, no masked copy of it.
-    struct Raw { void *p; size_t bytes; };
-    struct WinSet { Raw r[4]; } wset[2];      // raw frames, raw target frames, NAT rows, tables (win_start | targ_frame | nat_row)
-    int wcur;                                 // staging set of the resident window chunk
-    bool windows;                             // the resident chunk is a window chunk
-    struct { const float *fea, *tg, *nat; const int *ws, *tf, *nr; int D, win; } wv;   // views of set wcur
-    float *x0s, *tgs;                         // [Bp][ld_0], [Bp][ld_L]: the staged bunch (= tile stage_cur of the pair below)
-    float *x0s2[2], *tgs2[2]; int stage_cur;  // two staged tiles: while bunch i trains out of one, the output layer's reduce launch
-                                              // of bunch i stacks bunch i+1 into the other (bp_out_reduce_stage)
-    int next_first;                           // chunk frame of the bunch that follows the one being enqueued (-1: none / not a window chunk)
-    struct { bool valid; int first, tile; uint32_t step; unsigned gen; } pre;   // what the other tile holds
-    unsigned wgen;                            // bumped by every window upload (a pre-staged tile of the old chunk is void)
-    hipStream_t copy_stream;
-    hipEvent_t ev_copy;            // copy_stream: this chunk's H2D copies are done
-    hipEvent_t ev_retired;         // main stream: the stacked buffer pair that is NOT current is no longer read
-    hipEvent_t ev_wretired;        // main stream: the window staging set that is NOT current is no longer read
-    bool retired_valid, wretired_valid;
-    float *in_alt, *targ_alt;
-    // compute_dtype == 1 (bp_bf16.h): bf16 copies, each in both orientations
-    bool bf;
-    int Bp;                                                  // bunch rows rounded up to 64
-    bf16_t *Wb[BP_MAXLAYER];                                 // ONE bf16 shadow of the weights, [prev][cur] (the forward reads it through the LDS transpose read)
-    bf16_t *yb[BP_MAXLAYER], *ybT[BP_MAXLAYER];              // [Bp][ld_l], [ld_l][Bp]   (l = 0: the input bunch)
-    bf16_t *dxb[BP_MAXLAYER], *dxbT[BP_MAXLAYER];
-};
-
-// bp_profile_step: one HIP event after every launch of the step on the launch stream; the duration attributed to a
-// launch is the time between the previous event and its own (= kernel + the dependent-launch boundary in front of it).
-struct StepProf {
-    std::vector<hipEvent_t> ev; std::vector<int> kind; size_t used;
-};
-static hipError_t prof_mark(bp_handle *h, int kind)
+hipError_t prof_mark(bp_handle *h, int kind)
 {
     StepProf *p = h->prof;
     if (!p) return hipSuccess;
@@ -126,7 +39,7 @@ static uint32_t drop_threshold(float p)
     return (uint32_t)t;
 }
 
-extern "C" const char *bp_last_error(void) { return g_err.c_str(); }
+extern "C" const char *bp_last_error(void) { return g_bp_err.c_str(); }
 extern "C" int bp_abi_version(void) { return 4; }   // 4: host-driven DP split removed; bp_rdv_*, bp_dp_attach_ex (RCCL transport), bp_dp_peer_info
 extern "C" const char *bp_build_target(void) { return "gfx950"; }
 extern "C" int bp_device_count(int *n)
@@ -136,10 +49,7 @@ extern "C" int bp_device_count(int *n)
     return BP_OK;
 }
 
-// Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM
-// loaders (no predicates, see GemmArgs) stay inside the allocation.
-static const size_t SLACK = 4096;
-static int dev_alloc(bp_handle *h, float **p, size_t n_floats)
+int dev_alloc(bp_handle *h, float **p, size_t n_floats)
 {
     n_floats += SLACK;
     void *q = nullptr;
@@ -174,15 +84,11 @@ extern "C" int bp_destroy(bp_handle *h)
     return BP_OK;
 }
 
-static int dp_check(bp_handle *h);
 static int check_hyper(float, float, float, int, float, float, const char *);
-static hipError_t dp_bunch(bp_handle *h, int first);
 static int ensure_stacked(bp_handle *h);
 static hipError_t stage_bunch(bp_handle *h, int first, int rows, bool train);
 static StageArgs stage_args(bp_handle *h, int first, int rows, bool train, int tile, uint32_t step);
 static int stage_blocks(const bp_handle *h, const StageArgs &a);
-static hipError_t dp_flush(bp_handle *h);
-static int dp_gather_deltas(bp_handle *h);
 static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs);
 static hipError_t bf_shadow(bp_handle *h, int l);
 
@@ -221,12 +127,11 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->th_hid = cfg->dropoutflag == 1 ? drop_threshold(cfg->hid_omit) : 0u;
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
     h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
-    h->grouped = getenv("BP_NO_GROUPED") == nullptr;
     h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
     h->last_ms = 0.f; h->last_bunches = 0; h->dp = nullptr; h->params = h->deltas = nullptr;
     h->next_first = -1; h->pre.valid = false; h->wgen = 0; h->stage_cur = 0;
 
-#define CK(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_err; bp_destroy(h); g_err = m; return _r; } } while (0)
+#define CK(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_bp_err; bp_destroy(h); g_bp_err = m; return _r; } } while (0)
 #define HK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(_e); bp_destroy(h); return fail(BP_ERR_DEVICE, m); } } while (0)
     HK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
@@ -358,8 +263,8 @@ static EpiArgs epi_zero()
 
 // forward of weight layer l on M frames.  y_prev [M][ld_{l-1}].  train: hidden outputs get the
 // hid_omit mask; output layer writes dEdX_L (and out when out != null).
-static hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, const float *targ,
-                             float *out, bool train, float alpha)
+hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, const float *targ,
+                      float *out, bool train, float alpha)
 {
     const int L = h->L, prev = h->ld[l - 1], cur = h->ld[l];
     GemmArgs g; memset(&g, 0, sizeof(g));
@@ -496,14 +401,13 @@ static hipError_t run_multi_k(hipStream_t st, Prepared *ps, int n)
     return hipGetLastError();
 }
 
-// The wgrad problems ps[0..n) (all fused or all store): grouped launches of up to 4 problems, or one each.
-static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
+// The wgrad problems ps[0..n) (all fused or all store): grouped launches of up to 4 problems.
+static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n)
 {
     for (int i = 0; i < n;) {
-        const int m = grouped ? (n - i < 4 ? n - i : 4) : 1;
-        static const bool no_static = getenv("BP_WGRAD_DYNAMIC") != nullptr;    // development A/B switch
+        const int m = n - i < 4 ? n - i : 4;
         // bunches of 128 / 256 / 512 frames (the shipped .pl uses 128, BASELINE.json 256 and 512): LDS-DMA kernel, unrolled
-        int kk = !no_static ? ps[i].g.K : 0;
+        int kk = ps[i].g.K;
         for (int j = 0; j < m; ++j) if (ps[i + j].g.K != kk) kk = 0;
         hipError_t er;
         if (kk == 256 && ps[i].fused) er = run_multi_k<bp_wgrad_dma<16, 4, 4, 256>>(st, ps + i, m);
@@ -520,24 +424,24 @@ static hipError_t run_wgrads(hipStream_t st, Prepared *ps, int n, bool grouped)
     return hipSuccess;
 }
 
-static hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M)
+hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M)
 {
     Prepared p = prep_dgrad(h, l, M);
     if (p.cfg == CFG_DGRAD_WIDE128) return run_multi<KDgradWide128, 32, 64>(st, &p, 1);
     return p.cfg == CFG_DGRAD_WIDE ? run_multi<KDgradWide, 32, 64>(st, &p, 1) : run_multi<KDgradNarrow, 32, 32>(st, &p, 1);
 }
-static hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, bool fused)
+hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, bool fused)
 {
     Prepared p = prep_wgrad(h, l, M, y_prev, fused);
-    return run_wgrads(st, &p, 1, false);
+    return run_wgrads(st, &p, 1);
 }
 
 // visible-layer dropout active: bunches read the masked copy of the chunk
-static inline bool use_mask(const bp_handle *h) { return !h->windows && h->in_drop && h->th_vis; }
+bool step_use_mask(const bp_handle *h) { return !h->windows && h->in_drop && h->th_vis; }
 
-static hipError_t mask_range(bp_handle *h, int first, int n)
+hipError_t step_mask_range(bp_handle *h, int first, int n)
 {
-    if (!use_mask(h) || n <= 0) return hipSuccess;
+    if (!step_use_mask(h) || n <= 0) return hipSuccess;
     dim3 grid((n + 3) / 4, (h->ld[0] + 255) / 256);
     hipLaunchKernelGGL(bp_mask_input, grid, dim3(256), 0, h->stream, h->in, h->in_drop, h->ld[0], h->s[0], first, n,
                        h->B, h->cfg.rank_frame_offset, h->th_vis, (uint32_t)h->cfg.seed,
@@ -561,31 +465,30 @@ static hipError_t bf_convert(bp_handle *h, const float *src, int lds, int rows, 
                        rows, cols, out, ldo, outT, ldt, rows_pad, cols_pad);
     return hipGetLastError();
 }
-// fp32 master weights of layer l -> bf16 shadow in both orientations (creation, data-parallel update)
+// fp32 master weights of layer l -> the bf16 shadow (creation, data-parallel update)
 static hipError_t bf_shadow(bp_handle *h, int l)
 {
     const int prev = h->ld[l - 1], cur = h->ld[l];
     return bf_convert(h, h->W[l], cur, prev, cur, h->Wb[l], cur, nullptr, 0, prev, cur);
 }
-// BM = 32 tiles (128-thread workgroups) when 64-row tiles would leave CUs without work
+hipError_t step_shadow(bp_handle *h, int l) { return h->bf ? bf_shadow(h, l) : hipSuccess; }
+// One tile configuration per shape: 128-row tiles while they still give every CU a workgroup (LDS-DMA staged for the
+// hidden forward / dgrad), else 64-row, else 32-row tiles (128-thread workgroups).
 template <int EPI, bool BKN = false>
 static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int M, int N)
 {
     g.tiles_n = N / 64;
-    static const bool no128 = getenv("BP_BF16_NO128") != nullptr;                 // development A/B switch
-    if (!no128 && M % 128 == 0 && (M / 128) * g.tiles_n >= 256) {                 // 128-row tiles still fill the chip
+    if (M % 128 == 0 && (M / 128) * g.tiles_n >= 256) {
         g.tiles_m = M / 128;
-        static const bool no_dma = getenv("BP_BF16_GEMM_NO_DMA") != nullptr;      // development A/B switch
         if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_DGRAD) {              // LDS-DMA staged loop (bp_bf16.h)
-            if (!no_dma && (g.tiles_n & 7) == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && e.ldc % 8 == 0 && e.ldct % 8 == 0 && e.n_limit == N) {
+            if ((g.tiles_n & 7) == 0 && g.lda % 8 == 0 && g.ldb % 8 == 0 && e.ldc % 8 == 0 && e.ldct % 8 == 0 && e.n_limit == N) {
                 // k-tile offset between the m-tiles that share a weight panel (bp_bf16.h).  Measured in the step, configs[4], us per
                 // launch: forward (weights cold behind the update launch) 38.1 in phase, 36.3 four tiles apart, 33.7 a quarter of K
                 // apart; dgrad (weights read by the forward 0.3 ms earlier) 31.4 in phase, 30.4 two tiles apart, 32.3 a quarter apart.
                 // A quarter of K apart the four sharers no longer meet in L2 and the forward fetches its panel FOUR times (164 MB
                 // instead of 68 MB per launch at the L2's memory side, profiles/r04_bf16_gemm_probe.txt): 2.6 us per launch are not
-                // worth 2.4x the fabric traffic, so both stay within reach of each other's lines.  BP_BF16_ROT_FWD overrides (A/B).
-                static const int rot_fwd = getenv("BP_BF16_ROT_FWD") ? atoi(getenv("BP_BF16_ROT_FWD")) : 4;
-                g.k_rot = EPI == BEPI_FWD_HIDDEN ? rot_fwd : 2;
+                // worth 2.4x the fabric traffic, so both stay within reach of each other's lines.
+                g.k_rot = EPI == BEPI_FWD_HIDDEN ? 4 : 2;
                 hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128, BKN, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
                 return hipGetLastError();
             }
@@ -637,7 +540,8 @@ static hipError_t bf_dgrad(bp_handle *h, int l)
     e.C = h->dxb[l - 1]; e.ldc = prev; e.CT = h->dxbT[l - 1]; e.ldct = h->Bp; e.yprev = h->yb[l - 1]; e.ldy = prev;
     return bf_launch<BEPI_DGRAD>(h, g, e, h->Bp, prev);
 }
-// G_l = y_{l-1}^T . dEdX_l  (+ fused update and shadow refresh, or store into the flat buffer), bias gradient
+// G_l = y_{l-1}^T . dEdX_l  (+ fused update and shadow refresh, or store into the flat buffer), bias gradient: the
+// per-layer form for bunch sizes the unrolled LDS-DMA launch below is not built for
 static hipError_t bf_wgrad(bp_handle *h, int l, bool fused)
 {
     const int prev = h->ld[l - 1], cur = h->ld[l];
@@ -664,11 +568,7 @@ static hipError_t bf_wgrad(bp_handle *h, int l, bool fused)
 }
 // The LDS-DMA wgrad of bp_wgrad_dma_bf16.h: static bunch sizes, layers ls[0..n) in one grouped launch (bias gradient
 // fused); other bunch sizes keep bf_wgrad (GEMM kernel + bias kernel per layer).
-static bool bf_dma_ok(const bp_handle *h)
-{
-    static const bool off = getenv("BP_BF16_NO_DMA") != nullptr;                  // development A/B switch
-    return !off && (h->Bp == 128 || h->Bp == 256 || h->Bp == 512 || h->Bp == 1024);
-}
+static bool bf_dma_ok(const bp_handle *h) { return h->Bp == 128 || h->Bp == 256 || h->Bp == 512 || h->Bp == 1024; }
 static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
 {
     const float m = h->cfg.momentum, lr = h->cfg.lrate;
@@ -697,12 +597,11 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
             t += (p.tiles_m * p.tiles_n + 7) & ~7;             // (problem-relative block index keeps the XCD bits, see run_multi)
         }
         a.first_tile[cnt] = t; a.n = cnt;
+        // fused update: six waves (two of them own W / delta), 64-frame k-tiles in a ring of 3 when the bunch has at least 4;
+        // data-parallel gradient store: the four-wave loop alone
 #define BF_DMA_LAUNCH(K)                                                                                             \
-        do { static const bool four = getenv("BP_BF16_WGRAD_FOUR_WAVES") != nullptr;   /* development A/B switch */     \
-             /* fused update: six waves (two of them own W / delta), 64-frame k-tiles in a ring of 3 when the bunch has at least 4 */ \
-             if (fused && !four) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(t), dim3(384), 0, h->stream, a); \
-             else if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, false>), dim3(t), dim3(256), 0, h->stream, a);    \
-             else hipLaunchKernelGGL((bp_wgrad_dma_bf16<K, true>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
+        do { if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(t), dim3(384), 0, h->stream, a); \
+             else hipLaunchKernelGGL((bp_wgrad_dma_bf16_store<K>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
         switch (h->Bp) {
         case 128: BF_DMA_LAUNCH(128); break;
         case 256: BF_DMA_LAUNCH(256); break;
@@ -717,66 +616,88 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
 }
 // (measured round 3: 128x64 workgroup tiles -- 25 % fewer operand bytes through L2 -> LDS, 3 workgroups per CU -- are no
 // faster than these 64x64 ones on the configs[4] shape: 0.846 vs 0.835 ms per step)
-static hipError_t bf_bunch(bp_handle *h, const float *x0, const float *tg, bool fused)
+static hipError_t bf_wgrads(bp_handle *h, const int *ls, int n, bool fused)
 {
-    const int L = h->L;
-    hipError_t er;
-#define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
-    CKE(bf_input(h, x0, h->B));
-    for (int l = 1; l < L; ++l) CKE(bf_fwd(h, l, h->B, tg, nullptr, true, 1.0f));
-    for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));       // every dgrad sees pre-update (shadow) weights
-    if (bf_dma_ok(h)) {
-        int ls[BP_MAXLAYER];
-        for (int l = 1; l < L; ++l) ls[l - 1] = l;
-        CKE(bf_wgrads_dma(h, ls, L - 1, fused));
-    } else {
-        for (int l = 1; l < L; ++l) CKE(bf_wgrad(h, l, fused));
-    }
-#undef CKE
+    if (bf_dma_ok(h)) return bf_wgrads_dma(h, ls, n, fused);
+    for (int i = 0; i < n; ++i) { const hipError_t er = bf_wgrad(h, ls[i], fused); if (er != hipSuccess) return er; }
     return hipSuccess;
+}
+
+// ------------------------------------------------------------------ the pieces of one bunch
+// Where the rows of the bunch starting at chunk frame `first` lie: window chunks are stacked (and masked) into the staging
+// tile now, stacked chunks are read in place or from their masked copy.
+hipError_t step_inputs(bp_handle *h, int first, const float **x0, const float **tg)
+{
+    const int L = h->L, B = h->B;
+    if (h->windows) {
+        const hipError_t er = stage_bunch(h, first, B, true);
+        *x0 = h->x0s; *tg = h->tgs;
+        return er;
+    }
+    *x0 = h->in + (size_t)first * h->ld[0];
+    *tg = h->targ + (size_t)first * h->ld[L - 1];
+    if (h->inj_x0) *x0 = h->inj_x0;                     // bp_train_resident_masked: input rows with the injected visible mask
+    else if (step_use_mask(h)) {
+        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
+                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step && (first - h->mask_lo) % B == 0;
+        if (!ok) { const hipError_t er = step_mask_range(h, first, B); if (er != hipSuccess) return er; }
+        *x0 = h->in_drop + (size_t)first * h->ld[0];
+    }
+    return hipSuccess;
+}
+hipError_t step_forward(bp_handle *h, int l, const float *x0, const float *tg)
+{
+    if (h->bf) {
+        if (l == 1) { const hipError_t er = bf_input(h, x0, h->B); if (er != hipSuccess) return er; }
+        return bf_fwd(h, l, h->B, tg, nullptr, true, 1.0f);
+    }
+    return launch_fwd(h, h->stream, l, h->B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f);
+}
+hipError_t step_dgrad(bp_handle *h, int l) { return h->bf ? bf_dgrad(h, l) : launch_dgrad(h, h->stream, l, h->B); }
+// (fp32: the LDS-DMA store kernel of the static bunch sizes is the one that counts its tiles, up to 4 layers per launch)
+bool step_wgrads_count(const bp_handle *h) { return !h->bf && (h->B == 128 || h->B == 256 || h->B == 512) && h->L - 1 <= 4; }
+unsigned step_wgrad_tiles(const bp_handle *h, int l) { return (unsigned)(((h->ld[l - 1] + 63) / 64) * ((h->ld[l] + 63) / 64)); }
+hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done)
+{
+    if (h->bf) return bf_wgrads(h, ls, n, false);
+    Prepared ws[BP_MAXLAYER];
+    for (int i = 0; i < n; ++i) {
+        ws[i] = prep_wgrad(h, ls[i], h->B, ls[i] == 1 ? x0 : h->y[ls[i] - 1], false);
+        if (done) ws[i].e.done = done[ls[i]];
+    }
+    return run_wgrads(h->stream, ws, n);
 }
 
 // One bunch starting at chunk frame `first`: forward + backward.  fused: momentum update inside
 // the wgrad epilogues (train_bunch_single); else gradients to the flat buffer.  Everything is
 // enqueued on one stream in the reference's order (BP_GPU.cu:518-671); every dgrad of the step
 // sees pre-update weights because wgrad+update(l) always follows dgrad(l).
-static hipError_t bunch(bp_handle *h, int first, bool fused)
+hipError_t bunch(bp_handle *h, int first, bool fused)
 {
     const int L = h->L, B = h->B;
     hipError_t er;
 #define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
     const float *x0, *tg;
-    if (h->windows) {                                   // window chunk: stack (and mask) this bunch's rows now
-        CKE(stage_bunch(h, first, B, true));
-        x0 = h->x0s; tg = h->tgs;
-    } else {
-        x0 = h->in + (size_t)first * h->ld[0];
-        tg = h->targ + (size_t)first * h->ld[L - 1];
-        if (h->inj_x0) x0 = h->inj_x0;                  // bp_train_resident_masked: input rows with the injected visible mask
-        else if (use_mask(h)) {
-            const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
-                            (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step &&
-                            (first - h->mask_lo) % B == 0;
-            if (!ok) CKE(mask_range(h, first, B));
-            x0 = h->in_drop + (size_t)first * h->ld[0];
-        }
+    CKE(step_inputs(h, first, &x0, &tg));
+    int ls[BP_MAXLAYER];
+    for (int l = 1; l < L; ++l) ls[l - 1] = l;          // wgrad problems: layer 1 (the largest) first
+    if (h->bf) {
+        for (int l = 1; l < L; ++l) CKE(step_forward(h, l, x0, tg));
+        for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));   // every dgrad sees pre-update (shadow) weights
+        return bf_wgrads(h, ls, L - 1, fused);
     }
-    if (h->bf) return bf_bunch(h, x0, tg, fused);
     for (int l = 1; l < L; ++l) {
         CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
         CKE(prof_mark(h, l == 1 ? BP_PROF_FWD_L1 : (l == L - 1 ? BP_PROF_FWD_OUT : BP_PROF_FWD_HIDDEN)));
     }
     // Every dgrad of the step reads pre-update weights (BP_GPU.cu:636 runs before :643-652 of the same
     // layer and the lower layers' updates come later), so the wgrad+update problems can all wait until
-    // the last dgrad and share grouped launches (bp_gemm_multi), layer 1 (the largest) first.
-    Prepared ws[BP_MAXLAYER]; int nw = 0;
-    for (int l = L - 1; l >= 1; --l) {
-        if (l != 1) { CKE(launch_dgrad(h, h->stream, l, B)); CKE(prof_mark(h, l == L - 1 ? BP_PROF_DGRAD_OUT : BP_PROF_DGRAD_HIDDEN)); }
-        if (h->grouped) ws[nw++] = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
-        else { CKE(launch_wgrad(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], fused)); CKE(prof_mark(h, BP_PROF_WGRAD)); }
-    }
-    for (int i = 0; i < nw / 2; ++i) { Prepared t = ws[i]; ws[i] = ws[nw - 1 - i]; ws[nw - 1 - i] = t; }
-    if (nw) { CKE(run_wgrads(h->stream, ws, nw, true)); CKE(prof_mark(h, BP_PROF_WGRAD)); }
+    // the last dgrad and share grouped launches (bp_gemm_multi).
+    for (int l = L - 1; l >= 2; --l) { CKE(launch_dgrad(h, h->stream, l, B)); CKE(prof_mark(h, l == L - 1 ? BP_PROF_DGRAD_OUT : BP_PROF_DGRAD_HIDDEN)); }
+    Prepared ws[BP_MAXLAYER];
+    for (int l = 1; l < L; ++l) ws[l - 1] = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], fused);
+    CKE(run_wgrads(h->stream, ws, L - 1));
+    CKE(prof_mark(h, BP_PROF_WGRAD));
 #undef CKE
     return hipSuccess;
 }
@@ -949,7 +870,7 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
         h->wv.D = D; h->wv.win = ctx * D;
     }
     h->windows = true;
-    h->wgen++; h->pre.valid = false;
+    h->wgen++; h->pre.valid = false; h->next_first = -1;
     h->chunk_frames = n;
     h->mask_lo = h->mask_hi = -1;
     return BP_OK;
@@ -996,14 +917,18 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     HIPCHK(hipSetDevice(h->cfg.device));
     const int nb = n_frames / h->B;          // partial last bunch ignored (BP_GPU.cu:315-318)
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (nb > 0 && use_mask(h)) HIPCHK(mask_range(h, first_frame, nb * h->B));
-    for (int i = 0; i < nb; ++i) {
+    if (nb > 0 && step_use_mask(h)) HIPCHK(step_mask_range(h, first_frame, nb * h->B));
+    hipError_t er = hipSuccess;
+    for (int i = 0; i < nb && er == hipSuccess; ++i) {
         h->next_first = (h->windows && !h->bf && i + 1 < nb) ? first_frame + (i + 1) * h->B : -1;
-        if (h->dp) HIPCHK(dp_bunch(h, first_frame + i * h->B));
-        else HIPCHK(bunch(h, first_frame + i * h->B, true));
-        h->step++;
+        er = h->dp ? dp_bunch(h, first_frame + i * h->B) : bunch(h, first_frame + i * h->B, true);
+        if (er == hipSuccess) h->step++;
     }
-    h->next_first = -1;
+    h->next_first = -1;                      // (also on the error path: a stale index would stage rows of a later, smaller chunk)
+    if (er != hipSuccess) {
+        h->pre.valid = false;
+        return fail(BP_ERR_DEVICE, std::string("bp_train_resident: ") + hipGetErrorString(er));
+    }
     if (h->dp && nb > 0) HIPCHK(dp_flush(h));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_bunches = nb;
@@ -1096,7 +1021,6 @@ extern "C" int bp_train_resident_masked(bp_handle *h, int first_frame, int n_fra
 // forward + backward of ONE local bunch with the weight gradients stored into the flat buffer [W_1|b_1|W_2|b_2|...]
 // instead of being applied: the kernels of the data-parallel step (wgrad "store" form), exposed so that a test can
 // compare the gradient itself with the oracle's.  State (weights, momentum, step counter) is untouched.
-static hipError_t bunch(bp_handle *h, int first, bool fused);
 extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
 {
     if (!h) return fail(BP_ERR_ARG, "null handle");
@@ -1109,6 +1033,7 @@ extern "C" int bp_grads_resident(bp_handle *h, int first_frame)
         return fail(BP_ERR_STATE, "bp_grads_resident: the resident window chunk was uploaded without targets (forward / CV upload)");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (!h->grad) { int r = dev_alloc(h, &h->grad, h->grad_floats); if (r != BP_OK) return r; }
+    h->next_first = -1;
     HIPCHK(bunch(h, first_frame, false));
     return BP_OK;
 }
@@ -1150,27 +1075,6 @@ extern "C" int bp_read_layer_output(bp_handle *h, int layer, float *host_dst, si
     HIPCHK(hipStreamSynchronize(h->stream));
     return BP_OK;
 }
-
-// ------------------------------------------------------------------ host rendezvous (bp_rdv.h), C ABI
-extern "C" int bp_rdv_open(const char *key, int world, int rank, double timeout_s, bp_rdv **out)
-{
-    const int rc = rdv_open(key, world, rank, timeout_s, out);
-    return rc == 0 ? BP_OK : fail(rc, g_rdv_err);
-}
-extern "C" int bp_rdv_barrier(bp_rdv *r)
-{
-    if (!r) return fail(BP_ERR_ARG, "null rendezvous");
-    const int rc = rdv_barrier(r);
-    return rc == 0 ? BP_OK : fail(rc, g_rdv_err);
-}
-extern "C" int bp_rdv_allgather(bp_rdv *r, const void *mine, size_t bytes, void *all)
-{
-    if (!r || !mine || !all) return fail(BP_ERR_ARG, "null argument");
-    const int rc = rdv_allgather(r, mine, bytes, all);
-    return rc == 0 ? BP_OK : fail(rc, g_rdv_err);
-}
-extern "C" int bp_rdv_close(bp_rdv *r) { rdv_close(r, false); return BP_OK; }
-
 // Pin caller-owned host memory (hipHostRegister): uploads from it are then true DMA transfers on the copy engines instead
 // of staged copies through the runtime's bounce buffers (the reference stages its uploads through pinned memory too,
 // devnew_vf / cublasSetVectorAsync, BP_GPU.cu:926-992).  Optional: every upload entry point accepts pageable memory.
@@ -1193,593 +1097,6 @@ extern "C" int bp_device_pci_bus_id(int device, char *buf, int len)
     HIPCHK(hipDeviceGetPCIBusId(buf, len, device));
     return BP_OK;
 }
-
-// ------------------------------------------------------------------ in-library data-parallel exchange (bp_dp.h)
-// What every rank publishes through the rendezvous block (RdvShm::blob).
-struct DpBlob {
-    int device; char pci[20];
-    hipIpcMemHandle_t params, grad, deltas, flags, probe_p, probe_g;
-};
-static_assert(sizeof(DpBlob) <= BP_RDV_BLOB_BYTES, "rendezvous blob too small");
-
-// RCCL transport (north_star names it): resolved at run time from librccl.so so that the library itself
-// carries no link dependency on it.  Signatures from rccl.h (ROCm 7.2).
-struct RcclApi {
-    void *lib;
-    int (*GetUniqueId)(void *id);
-    int (*CommInitRank)(void **comm, int nranks, ncclUniqueIdBytes id, int rank);
-    int (*ReduceScatter)(const void *send, void *recv, size_t recvcount, int dtype, int op, void *comm, hipStream_t st);
-    int (*AllGather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t st);
-    int (*CommDestroy)(void *comm);
-    const char *(*GetErrorString)(int);
-};
-
-struct bp_dp {
-    int world, rank;
-    bp_rdv *rdv;
-    int backend;                  // 0: native peer kernels over hipIpc mappings | 1: RCCL reduce-scatter / all-gather
-    int acquire_mode;             // 0: kernel boundary behind the wait kernel | 1: + explicit system-scope acquire on every XCD
-    bool distinct_devices;        // at least two ranks sit on different physical devices
-    int peer_device[BP_DP_MAXRANKS]; char peer_pci[BP_DP_MAXRANKS][20];
-    float *p_params[BP_DP_MAXRANKS], *p_grad[BP_DP_MAXRANKS], *p_deltas[BP_DP_MAXRANKS];
-    float *p_probe_p[BP_DP_MAXRANKS], *p_probe_g[BP_DP_MAXRANKS];
-    unsigned *p_flags[BP_DP_MAXRANKS];
-    float *grad_fine, *grad_prev; // fine-grained gradient buffer used while attached / the handle's own one (restored at detach)
-    float *probe_p, *probe_g;     // self-test probes: ordinary (like the parameter arena) / fine-grained (like the gradient buffer)
-    unsigned *flags;              // own flag words (fine-grained device memory, exported)
-    unsigned *arrive;             // [BP_MAXLAYER] last-arriver counters of bp_dp_reduce_update
-    unsigned *done;               // [BP_MAXLAYER] tiles of layer l's gradient segment stored so far (counted by the wgrad-store kernel itself)
-    unsigned done_target[BP_MAXLAYER];   // host: value done[l] reaches when the current minibatch's tiles are in
-    bool counters_ok;             // the in-kernel hand-off passed the attach-time self-test (else: event + kernel boundary per group of layers)
-    unsigned *err;                // pinned host word the wait kernels raise on timeout
-    hipStream_t comm;             // exchange stream: signal -> wait -> reduce/update/all-gather per layer
-    hipEvent_t ev_g[BP_MAXLAYER]; // main stream: gradient segment l is complete
-    hipEvent_t ev_w[BP_MAXLAYER]; // comm stream (RCCL backend): the weights of layer l have been gathered
-    hipEvent_t ev_comm;           // comm stream: everything queued so far is done (flush)
-    unsigned epoch;               // minibatches exchanged so far (flag value of the current one)
-    size_t lo[BP_MAXLAYER], hi[BP_MAXLAYER];   // this rank's slice of layer l's flat segment
-    unsigned long long budget_ticks;
-    bool peers_open;
-    RcclApi rccl; void *rccl_comm; float *red;   // RCCL backend: communicator, reduce-scatter landing buffer (largest slice)
-};
-
-static double dp_timeout_s()
-{
-    const char *e = getenv("BP_DP_TIMEOUT_S");
-    const double v = e ? atof(e) : 60.0;
-    return v > 0.5 ? v : 0.5;
-}
-
-static void dp_release(bp_handle *h, bool failed)
-{
-    bp_dp *d = h->dp;
-    if (!d) return;
-    if (d->comm) (void)hipStreamSynchronize(d->comm);
-    if (d->rccl_comm && d->rccl.CommDestroy) (void)d->rccl.CommDestroy(d->rccl_comm);
-    if (d->rccl.lib) dlclose(d->rccl.lib);
-    if (d->peers_open)
-        for (int p = 0; p < d->world; ++p) {
-            if (p == d->rank) continue;
-            for (void *q : {(void *)d->p_params[p], (void *)d->p_grad[p], (void *)d->p_deltas[p], (void *)d->p_flags[p],
-                            (void *)d->p_probe_p[p], (void *)d->p_probe_g[p]})
-                if (q) (void)hipIpcCloseMemHandle(q);
-        }
-    for (auto &e : d->ev_g) if (e) (void)hipEventDestroy(e);
-    for (auto &e : d->ev_w) if (e) (void)hipEventDestroy(e);
-    if (d->ev_comm) (void)hipEventDestroy(d->ev_comm);
-    if (d->comm) (void)hipStreamDestroy(d->comm);
-    if (d->grad_fine) { if (h->grad == d->grad_fine) h->grad = d->grad_prev; (void)hipFree(d->grad_fine); }
-    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->done, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red})
-        if (q) (void)hipFree(q);
-    if (d->err) (void)hipHostFree(d->err);
-    rdv_close(d->rdv, failed);
-    delete d;
-    h->dp = nullptr;
-}
-
-extern "C" int bp_dp_detach(bp_handle *h)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (!h->dp) return BP_OK;
-    (void)hipSetDevice(h->cfg.device);
-    (void)hipStreamSynchronize(h->stream);
-    bp_dp *d = h->dp;
-    // nobody may unmap a buffer a peer kernel could still touch: everyone arrives here quiescent first
-    int r = BP_OK;
-    if (d->peers_open && rdv_barrier(d->rdv) != 0) r = fail(BP_ERR_STATE, g_rdv_err);
-    dp_release(h, r != BP_OK);
-    return r;
-}
-
-static DpPeers dp_peers(const bp_dp *d)
-{
-    DpPeers p; memset(&p, 0, sizeof(p));
-    for (int i = 0; i < d->world; ++i) p.flags[i] = d->p_flags[i];
-    return p;
-}
-
-// Attach-time check of the memory-model contract on the group's real devices (bp_dp.h, "attach-time self-test").
-// Returns the number of mismatching words seen by THIS rank over all rounds (W direction in *bad_w, G in *bad_g).
-static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad_w, unsigned *bad_g, unsigned *bad_c)
-{
-    bp_dp *d = h->dp;
-    unsigned *cnt = nullptr;
-    float *sink = nullptr;
-    HIPCHK(hipHostMalloc((void **)&cnt, 3 * sizeof(unsigned), hipHostMallocMapped));
-    cnt[0] = cnt[1] = cnt[2] = 0u;
-    HIPCHK(hipMalloc((void **)&sink, 64));
-    const DpPeers peers = dp_peers(d);
-    DpReduceArgs a; memset(&a, 0, sizeof(a));
-    for (int p = 0; p < d->world; ++p) { a.params[p] = d->p_probe_p[p]; a.grads[p] = d->p_probe_g[p]; }
-    a.world = d->world; a.rank = d->rank; a.peers = peers;
-    int rc = BP_OK;
-    for (int r = 1; r <= rounds && rc == BP_OK; ++r) {
-        const unsigned ep = ep_base + (unsigned)r;             // flag values of the probe words only ever grow (fresh flag array per attach)
-        // ---- (W): warm this device's caches with the OLD contents, let the peers overwrite, wait, re-read plainly
-        hipLaunchKernelGGL(bp_dp_probe_touch, dim3(64), dim3(256), 0, h->stream, d->probe_p, sink);
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }
-        a.flag_index = bp_dp_flag_index(BP_DP_FLAG_PROBE, 0, d->rank); a.epoch = ep;
-        hipLaunchKernelGGL(bp_dp_probe_push, dim3(1), dim3(256), 0, d->comm, a, (unsigned)r);
-        hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, h->stream, d->flags, bp_dp_flag_index(BP_DP_FLAG_PROBE, 0, 0), d->world, ep,
-                           d->budget_ticks, d->err, 3u);
-        if (d->acquire_mode) hipLaunchKernelGGL(bp_dp_l2_invalidate, dim3(64), dim3(64), 0, h->stream);
-        hipLaunchKernelGGL(bp_dp_probe_check, dim3(64), dim3(256), 0, h->stream, d->probe_p, d->world, (unsigned)r, cnt);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipStreamSynchronize(d->comm));
-        // ---- (G): fill the fine-grained probe with plain stores, signal behind the kernel boundary, peers read it
-        hipLaunchKernelGGL(bp_dp_probe_fill, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r, (unsigned)d->rank);
-        HIPCHK(hipEventRecord(d->ev_comm, h->stream));
-        HIPCHK(hipStreamWaitEvent(d->comm, d->ev_comm, 0));
-        hipLaunchKernelGGL(bp_dp_signal, dim3(1), dim3(64), 0, d->comm, peers, d->world, bp_dp_flag_index(BP_DP_FLAG_PROBE, 1, d->rank), ep);
-        hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, d->comm, d->flags, bp_dp_flag_index(BP_DP_FLAG_PROBE, 1, 0), d->world, ep,
-                           d->budget_ticks, d->err, 3u);
-        hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r, cnt + 1);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(d->comm));
-        if (*(volatile unsigned *)d->err) { rc = fail(BP_ERR_STATE, "data-parallel self-test: a peer's flag never arrived"); break; }
-        if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }    // nobody refills a probe a peer still reads
-        // ---- (C): the same direction with the step's IN-KERNEL hand-off -- the filling kernel counts its own workgroups, the
-        // exchange stream's bp_dp_sync (already queued, running beside it) sees the count, tells the peers, the peers read.
-        // No event and no kernel boundary between the stores and the readers' flag.
-        if (d->counters_ok) {
-            const unsigned ep2 = ep + 0x4000u;                     // (flag words only grow; probe word 2 is this direction's)
-            hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + BP_MAXLAYER, (ep_base + (unsigned)r) * 64u, peers, d->flags, d->world,
-                               bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, d->rank), bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, 0), ep2, d->budget_ticks, d->err, 3u);
-            hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r + 100u, cnt + 2);
-            hipLaunchKernelGGL(bp_dp_probe_fill_count, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r + 100u, (unsigned)d->rank, d->done + BP_MAXLAYER);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(h->stream));
-            HIPCHK(hipStreamSynchronize(d->comm));
-            if (*(volatile unsigned *)d->err) { rc = fail(BP_ERR_STATE, "data-parallel self-test: the in-kernel hand-off never completed"); break; }
-            if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }
-        }
-    }
-    *bad_w = cnt[0]; *bad_g = cnt[1]; *bad_c = cnt[2];
-    (void)hipHostFree(cnt); (void)hipFree(sink);
-    return rc;
-}
-
-static int dp_load_rccl(bp_dp *d)
-{
-    RcclApi &r = d->rccl;
-    r.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-    if (!r.lib) r.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!r.lib) return fail(BP_ERR_STATE, std::string("bp_dp_attach: RCCL transport requested but librccl.so cannot be loaded: ") + dlerror());
-    *(void **)&r.GetUniqueId = dlsym(r.lib, "ncclGetUniqueId");
-    *(void **)&r.CommInitRank = dlsym(r.lib, "ncclCommInitRank");
-    *(void **)&r.ReduceScatter = dlsym(r.lib, "ncclReduceScatter");
-    *(void **)&r.AllGather = dlsym(r.lib, "ncclAllGather");
-    *(void **)&r.CommDestroy = dlsym(r.lib, "ncclCommDestroy");
-    *(void **)&r.GetErrorString = dlsym(r.lib, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.ReduceScatter || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
-        return fail(BP_ERR_STATE, "bp_dp_attach: librccl.so lacks an expected symbol");
-    return BP_OK;
-}
-
-extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *key, int transport)
-{
-    if (!h || !key || !*key) return fail(BP_ERR_ARG, "bp_dp_attach: null argument");
-    if (world < 1 || world > BP_DP_MAXRANKS || rank < 0 || rank >= world)
-        return fail(BP_ERR_ARG, "bp_dp_attach: world must be 1..8 and 0 <= rank < world");
-    if (transport != BP_DP_TRANSPORT_NATIVE && transport != BP_DP_TRANSPORT_RCCL) return fail(BP_ERR_ARG, "bp_dp_attach: unknown transport");
-    if (transport == BP_DP_TRANSPORT_RCCL && (world & (world - 1)) != 0)
-        return fail(BP_ERR_ARG, "bp_dp_attach: the RCCL transport needs a world of 1, 2, 4 or 8 (equal slices)");
-    if (h->dp) return fail(BP_ERR_STATE, "bp_dp_attach: handle is already attached");
-    if (h->Bg != h->B * world || h->cfg.rank_frame_offset != rank * h->B)
-        return fail(BP_ERR_ARG, "bp_dp_attach: create the handle with global_bunchsize = world*bunchsize and rank_frame_offset = rank*bunchsize");
-    if (h->L - 1 >= 16) return fail(BP_ERR_ARG, "bp_dp_attach: too many layers");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    bp_dp *d = new bp_dp();
-    memset((void *)d, 0, sizeof(*d));
-    h->dp = d;
-    d->world = world; d->rank = rank; d->epoch = 0; d->peers_open = false; d->backend = transport;
-    d->budget_ticks = (unsigned long long)(dp_timeout_s() * 1.0e8);      // wall_clock64: 100 MHz
-#define DK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string("bp_dp_attach: ") + #x + ": " + hipGetErrorString(_e); \
-        dp_release(h, true); return fail(BP_ERR_DEVICE, m); } } while (0)
-#define DR(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_err; dp_release(h, true); g_err = m; return _r; } } while (0)
-    // the gradient buffer peers read: fine-grained (uncached in every mapping, written through by the wgrad kernels)
-    // (if the runtime refuses a fine-grained allocation of this size, an ordinary one still works with the system-scope
-    // loads of bp_dp_reduce_update on ONE device; across devices the self-test below decides)
-    if (transport == BP_DP_TRANSPORT_RCCL ||      // (RCCL's kernels read it locally: ordinary cached memory)
-        hipExtMallocWithFlags((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
-        d->grad_fine = nullptr;
-        DK(hipMalloc((void **)&d->grad_fine, (h->grad_floats + SLACK) * sizeof(float)));
-    }
-    DK(hipMemset(d->grad_fine, 0, (h->grad_floats + SLACK) * sizeof(float)));
-    d->grad_prev = h->grad; h->grad = d->grad_fine;
-    DK(hipExtMallocWithFlags((void **)&d->flags, BP_DP_FLAG_WORDS * sizeof(unsigned), hipDeviceMallocFinegrained));
-    DK(hipMemset(d->flags, 0, BP_DP_FLAG_WORDS * sizeof(unsigned)));
-    DK(hipMalloc((void **)&d->arrive, BP_MAXLAYER * sizeof(unsigned)));
-    DK(hipMemset(d->arrive, 0, BP_MAXLAYER * sizeof(unsigned)));
-    DK(hipMalloc((void **)&d->done, (BP_MAXLAYER + 1) * sizeof(unsigned)));       // (+1: the self-test's counter)
-    DK(hipMemset(d->done, 0, (BP_MAXLAYER + 1) * sizeof(unsigned)));
-    d->counters_ok = transport != BP_DP_TRANSPORT_RCCL && getenv("BP_DP_NO_COUNTERS") == nullptr;
-    DK(hipMalloc((void **)&d->probe_p, BP_DP_PROBE_FLOATS * sizeof(float)));
-    DK(hipMemset(d->probe_p, 0, BP_DP_PROBE_FLOATS * sizeof(float)));
-    if (hipExtMallocWithFlags((void **)&d->probe_g, BP_DP_PROBE_FLOATS * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
-        d->probe_g = nullptr;
-        DK(hipMalloc((void **)&d->probe_g, BP_DP_PROBE_FLOATS * sizeof(float)));
-    }
-    DK(hipMemset(d->probe_g, 0, BP_DP_PROBE_FLOATS * sizeof(float)));
-    DK(hipHostMalloc((void **)&d->err, sizeof(unsigned), hipHostMallocMapped));
-    *d->err = 0u;
-    {   // the exchange yields to the GEMMs of the main stream when both have workgroups to place
-        int lo_prio = 0, hi_prio = 0;
-        DK(hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio));
-        DK(hipStreamCreateWithPriority(&d->comm, hipStreamNonBlocking, lo_prio));
-    }
-    for (int l = 1; l < h->L; ++l) {
-        DK(hipEventCreateWithFlags(&d->ev_g[l], hipEventDisableTiming));
-        DK(hipEventCreateWithFlags(&d->ev_w[l], hipEventDisableTiming));
-    }
-    DK(hipEventCreateWithFlags(&d->ev_comm, hipEventDisableTiming));
-    DK(hipStreamSynchronize(h->stream));
-    size_t max_slice = 4;
-    for (int l = 1; l < h->L; ++l) {                           // equal float4-aligned slices of [W_l|b_l]
-        const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + world - 1) / world;
-        const size_t a = per4 * rank < cnt4 ? per4 * rank : cnt4, b = per4 * (rank + 1) < cnt4 ? per4 * (rank + 1) : cnt4;
-        d->lo[l] = h->g_off[l] + 4 * a; d->hi[l] = h->g_off[l] + 4 * b;
-        if (4 * per4 > max_slice) max_slice = 4 * per4;
-        if (transport == BP_DP_TRANSPORT_RCCL && per4 * world != cnt4) { dp_release(h, true); return fail(BP_ERR_ARG, "bp_dp_attach: RCCL transport: layer segment not divisible by the world"); }
-    }
-    // ---- rendezvous: publish device + hipIpc handles, map every peer's
-    {
-        bp_rdv *rv = nullptr;
-        if (rdv_open(key, world, rank, dp_timeout_s(), &rv) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: " + g_rdv_err); }
-        d->rdv = rv;
-    }
-    DpBlob mine; memset(&mine, 0, sizeof(mine));
-    mine.device = h->cfg.device;
-    DK(hipDeviceGetPCIBusId(mine.pci, (int)sizeof(mine.pci), h->cfg.device));
-    DK(hipIpcGetMemHandle(&mine.params, h->params));
-    DK(hipIpcGetMemHandle(&mine.grad, h->grad));
-    DK(hipIpcGetMemHandle(&mine.deltas, h->deltas));
-    DK(hipIpcGetMemHandle(&mine.flags, d->flags));
-    DK(hipIpcGetMemHandle(&mine.probe_p, d->probe_p));
-    DK(hipIpcGetMemHandle(&mine.probe_g, d->probe_g));
-    memcpy(d->rdv->shm->blob[rank], &mine, sizeof(mine));
-    if (transport == BP_DP_TRANSPORT_RCCL) {
-        DR(dp_load_rccl(d));
-        if (rank == 0) {
-            static_assert(sizeof(ncclUniqueIdBytes) <= sizeof(d->rdv->shm->shared), "unique id does not fit");
-            ncclUniqueIdBytes id;
-            const int e = d->rccl.GetUniqueId(&id);
-            if (e != 0) { dp_release(h, true); return fail(BP_ERR_DEVICE, std::string("ncclGetUniqueId: ") + d->rccl.GetErrorString(e)); }
-            memcpy(d->rdv->shm->shared, &id, sizeof(id));
-        }
-    }
-    if (rdv_barrier(d->rdv) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }
-    d->peers_open = true;
-    for (int p = 0; p < world; ++p) {
-        DpBlob pb; memcpy(&pb, d->rdv->shm->blob[p], sizeof(pb));
-        d->peer_device[p] = pb.device; memcpy(d->peer_pci[p], pb.pci, sizeof(pb.pci)); d->peer_pci[p][sizeof(pb.pci) - 1] = 0;
-        if (strcmp(pb.pci, mine.pci) != 0) d->distinct_devices = true;
-        if (p == rank) {
-            d->p_params[p] = h->params; d->p_grad[p] = h->grad; d->p_deltas[p] = h->deltas; d->p_flags[p] = d->flags;
-            d->p_probe_p[p] = d->probe_p; d->p_probe_g[p] = d->probe_g;
-            continue;
-        }
-        DK(hipIpcOpenMemHandle((void **)&d->p_params[p], pb.params, hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_grad[p], pb.grad, hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_deltas[p], pb.deltas, hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_flags[p], pb.flags, hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_probe_p[p], pb.probe_p, hipIpcMemLazyEnablePeerAccess));
-        DK(hipIpcOpenMemHandle((void **)&d->p_probe_g[p], pb.probe_g, hipIpcMemLazyEnablePeerAccess));
-    }
-    if (rdv_barrier(d->rdv) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }   // every rank has mapped every peer
-    if (transport == BP_DP_TRANSPORT_RCCL) {
-        ncclUniqueIdBytes id; memcpy(&id, d->rdv->shm->shared, sizeof(id));
-        const int e = d->rccl.CommInitRank(&d->rccl_comm, world, id, rank);
-        if (e != 0) { std::string m = std::string("ncclCommInitRank: ") + d->rccl.GetErrorString(e); dp_release(h, true); return fail(BP_ERR_DEVICE, m); }
-        DK(hipMalloc((void **)&d->red, (max_slice + SLACK) * sizeof(float)));
-    } else if (world > 1) {
-        // ---- the memory-model contract of the native exchange, checked on these devices before anything relies on it
-        for (int mode = 0; mode < 2; ++mode) {
-            d->acquire_mode = mode;
-            unsigned bw = 0, bg = 0, bc = 0;
-            DR(dp_selftest(h, 4, 4u * (unsigned)mode, &bw, &bg, &bc));
-            unsigned mine2[3] = {bw, bg, bc}, all[3 * BP_DP_MAXRANKS];
-            if (rdv_allgather(d->rdv, mine2, sizeof(mine2), all) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }
-            unsigned tw = 0, tg = 0, tc = 0;
-            for (int p = 0; p < world; ++p) { tw += all[3 * p]; tg += all[3 * p + 1]; tc += all[3 * p + 2]; }
-            if (tc) d->counters_ok = false;                        // (every rank sees the same verdict) the event + kernel-boundary hand-off stays
-            if (tg) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: self-test failed: peers read stale gradient words from a fine-grained buffer (" + std::to_string(tg) + " words)"); }
-            if (!tw) break;
-            if (mode == 1) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: self-test failed: stale weights after a peer's write-through stores even with an explicit acquire (" + std::to_string(tw) + " words)"); }
-        }
-    }
-#undef DK
-#undef DR
-    return BP_OK;
-}
-extern "C" int bp_dp_attach(bp_handle *h, int world, int rank, const char *key) { return bp_dp_attach_ex(h, world, rank, key, BP_DP_TRANSPORT_NATIVE); }
-
-static int dp_check(bp_handle *h)
-{
-    if (h->dp && *(volatile unsigned *)h->dp->err) {
-        const unsigned e = *(volatile unsigned *)h->dp->err;
-        return fail(BP_ERR_STATE, "data-parallel exchange timed out on the device: waiting for rank " + std::to_string((e % 1000u) - 1u) +
-                                      (e / 1000u == 1 ? " (gradient ready)" : " (weights gathered)"));
-    }
-    return BP_OK;
-}
-
-// main stream: the weights of layer l gathered from every rank for minibatch `epoch` (none before the first)
-static hipError_t dp_wait_weights(bp_handle *h, int l, unsigned epoch)
-{
-    bp_dp *d = h->dp;
-    if (epoch == 0) return hipSuccess;
-    if (d->backend == BP_DP_TRANSPORT_RCCL) return hipStreamWaitEvent(h->stream, d->ev_w[l], 0);
-    hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, h->stream, d->flags, bp_dp_flag_index(BP_DP_FLAG_W, l, 0), d->world, epoch,
-                       d->budget_ticks, d->err, 2u);
-    if (d->acquire_mode) hipLaunchKernelGGL(bp_dp_l2_invalidate, dim3(64), dim3(64), 0, h->stream);
-    return hipGetLastError();
-}
-
-static void dp_update_args(bp_handle *h, int l, DpReduceArgs &a)
-{
-    bp_dp *d = h->dp;
-    memset(&a, 0, sizeof(a));
-    a.delta = h->deltas; a.lo = d->lo[l]; a.hi = d->hi[l];
-    a.w_end = h->g_off[l] + (size_t)h->ld[l - 1] * h->ld[l];
-    a.world = d->world; a.rank = d->rank;
-    const float m = h->cfg.momentum, lr = h->cfg.lrate;
-    a.mom = m; a.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; a.wc = h->cfg.weightcost; a.ndiv = (float)h->Bg;
-    a.arrive = d->arrive + l; a.peers = dp_peers(d); a.flag_index = bp_dp_flag_index(BP_DP_FLAG_W, l, d->rank); a.epoch = d->epoch;
-}
-static int dp_update_grid(const DpReduceArgs &a)
-{
-    const size_t n4 = (a.hi - a.lo) / 4;
-    static const int max_grid = getenv("BP_DP_GRID") ? atoi(getenv("BP_DP_GRID")) : 128;   // development A/B switch
-    // few, deep workgroups: at 2048 workgroups the exchange kernel crowds the GEMMs it runs beside out of the CUs'
-    // memory pipes (C2 step through the exchange path on one GPU: 0.51 ms at 2048, 0.34 at 512, 0.28 at 128, 0.31 at 64)
-    int grid = (int)((n4 + 256 * BP_DP_UNROLL - 1) / (256 * BP_DP_UNROLL));
-    if (grid > max_grid) grid = max_grid;
-    return grid < 1 ? 1 : grid;                                // (an empty slice still raises its flag)
-}
-
-// comm stream: reduce this rank's slice of layer l over all ranks, update it, write the new weights to every rank (native transport)
-static hipError_t dp_reduce_layer(bp_handle *h, int l)
-{
-    bp_dp *d = h->dp;
-    DpReduceArgs a;
-    dp_update_args(h, l, a);
-    for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
-    const int grid = dp_update_grid(a);
-    switch (d->world) {
-    case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    case 4: hipLaunchKernelGGL(bp_dp_reduce_update<4>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    case 8: hipLaunchKernelGGL(bp_dp_reduce_update<8>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    default: hipLaunchKernelGGL(bp_dp_reduce_update<0>, dim3(grid), dim3(256), 0, d->comm, a); break;
-    }
-    return hipGetLastError();
-}
-
-// comm stream, after the gradient segments of layers ls[0..n) are complete on the main stream (ONE event: every event
-// record costs the main stream a ~6 us bubble, profiles/r03_dp_world1_timeline.txt): tell every rank, wait for every
-// rank's segments, then per layer reduce this rank's slice, update it and write the new weights to every rank
-static hipError_t dp_exchange_layers(bp_handle *h, const int *ls, int n)
-{
-    bp_dp *d = h->dp;
-    hipError_t er;
-    if ((er = hipEventRecord(d->ev_g[ls[0]], h->stream)) != hipSuccess) return er;
-    if ((er = hipStreamWaitEvent(d->comm, d->ev_g[ls[0]], 0)) != hipSuccess) return er;
-    if (d->backend != BP_DP_TRANSPORT_RCCL) {
-        const DpPeers peers = dp_peers(d);
-        DpIdx sig, wt; sig.n = wt.n = n;
-        for (int i = 0; i < n; ++i) { sig.index[i] = bp_dp_flag_index(BP_DP_FLAG_GRAD, ls[i], d->rank); wt.index[i] = bp_dp_flag_index(BP_DP_FLAG_GRAD, ls[i], 0); }
-        hipLaunchKernelGGL(bp_dp_signal_n, dim3(1), dim3(64), 0, d->comm, peers, d->world, sig, d->epoch);
-        hipLaunchKernelGGL(bp_dp_wait_n, dim3(1), dim3(64), 0, d->comm, d->flags, wt, d->world, d->epoch, d->budget_ticks, d->err, 1u);
-    }
-    for (int i = 0; i < n; ++i) {
-        const int l = ls[i];
-        DpReduceArgs a;
-        dp_update_args(h, l, a);
-        if (d->backend == BP_DP_TRANSPORT_RCCL) {
-            // reduce-scatter of the segment into `red` (this rank's slice), sharded update on it, all-gather of the new W
-            // slice in place in the parameter arena; RCCL orders the ranks, the event orders the next forward of this layer
-            const size_t cnt = d->hi[l] - d->lo[l];
-            int e = d->rccl.ReduceScatter(h->grad + h->g_off[l], d->red, cnt, 7 /* ncclFloat32 */, 0 /* ncclSum */, d->rccl_comm, d->comm);
-            if (e != 0) return hipErrorUnknown;
-            a.grads[0] = d->red - a.lo;                            // the kernel indexes grads[p] + lo
-            a.params[0] = h->params;
-            a.world = 1; a.rank = 0;
-            a.peers.flags[0] = d->flags;                           // (flag raised on this rank only; nobody waits for it)
-            hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(dp_update_grid(a)), dim3(256), 0, d->comm, a);
-            if ((er = hipGetLastError()) != hipSuccess) return er;
-            e = d->rccl.AllGather(h->params + d->lo[l], h->params + h->g_off[l], cnt, 7, d->rccl_comm, d->comm);
-            if (e != 0) return hipErrorUnknown;
-            if ((er = hipEventRecord(d->ev_w[l], d->comm)) != hipSuccess) return er;
-            continue;
-        }
-        if ((er = dp_reduce_layer(h, l)) != hipSuccess) return er;
-    }
-    return hipSuccess;
-}
-
-// One data-parallel minibatch (this rank's shard starts at chunk frame `first`).  Per layer: wait for the gathered
-// weights of the previous minibatch right before the layer's forward; after all dgrads the weight gradients go out
-// largest segment first, each followed at once by its exchange on the comm stream -- so the exchange of layer l
-// overlaps the remaining weight gradients and the NEXT minibatch's forward of the layers before l.
-static hipError_t dp_bunch(bp_handle *h, int first)
-{
-    bp_dp *d = h->dp;
-    const int L = h->L, B = h->B;
-    hipError_t er;
-#define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
-    const float *x0, *tg;
-    if (h->windows) {                                   // window chunk: stack (and mask) this bunch's rows now
-        CKE(stage_bunch(h, first, B, true));
-        x0 = h->x0s; tg = h->tgs;
-    } else {
-        x0 = h->in + (size_t)first * h->ld[0];
-        tg = h->targ + (size_t)first * h->ld[L - 1];
-        if (use_mask(h)) {
-            const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
-                            (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step && (first - h->mask_lo) % B == 0;
-            if (!ok) CKE(mask_range(h, first, B));
-            x0 = h->in_drop + (size_t)first * h->ld[0];
-        }
-    }
-    const unsigned prev_epoch = d->epoch;
-    d->epoch++;
-    if (h->bf) {
-        for (int l = 1; l < L; ++l) {
-            CKE(dp_wait_weights(h, l, prev_epoch));
-            if (prev_epoch) CKE(bf_shadow(h, l));               // bf16 copies of the gathered fp32 weights
-            if (l == 1) CKE(bf_input(h, x0, B));
-            CKE(bf_fwd(h, l, B, tg, nullptr, true, 1.0f));
-        }
-        for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));
-        // layer 1 (the largest segment, needed first by the next forward) goes out alone; the rest as one group: its
-        // exchange queues behind layer 1's on the comm stream anyway, and one launch + one event replace L-2 of each
-        int rest[BP_MAXLAYER], nrest = 0;
-        for (int l = 2; l < L; ++l) rest[nrest++] = l;
-        const int one = 1;
-        if (bf_dma_ok(h)) {
-            CKE(bf_wgrads_dma(h, &one, 1, false)); CKE(dp_exchange_layers(h, &one, 1));
-            if (nrest) { CKE(bf_wgrads_dma(h, rest, nrest, false)); CKE(dp_exchange_layers(h, rest, nrest)); }
-        } else {
-            for (int l = 1; l < L; ++l) { CKE(bf_wgrad(h, l, false)); CKE(dp_exchange_layers(h, &l, 1)); }
-        }
-    } else {
-        for (int l = 1; l < L; ++l) {
-            CKE(dp_wait_weights(h, l, prev_epoch));
-            CKE(launch_fwd(h, h->stream, l, B, l == 1 ? x0 : h->y[l - 1], tg, nullptr, true, 1.0f));
-        }
-        for (int l = L - 1; l >= 2; --l) CKE(launch_dgrad(h, h->stream, l, B));
-        Prepared ws[BP_MAXLAYER]; int rest[BP_MAXLAYER], nrest = 0;
-        const int one = 1;
-        const bool static_k = B == 128 || B == 256 || B == 512;         // (the LDS-DMA store kernel, the one that counts its tiles)
-        if (d->counters_ok && d->backend != BP_DP_TRANSPORT_RCCL && static_k && L - 1 <= 4) {
-            // ONE grouped weight-gradient launch, layer 1's tiles first; every tile counts itself into done[l] (bp_wgrad_dma.h), and
-            // the exchange stream -- queued right here, running beside the launch -- picks each layer up as soon as its count is
-            // complete: no event on this stream (each cost it a ~7 us bubble), no split of the launch, and layer 1's exchange
-            // overlaps the other layers' tiles instead of waiting behind a launch boundary.
-            int nw = 0;
-            for (int l = 1; l < L; ++l) {
-                ws[nw] = prep_wgrad(h, l, B, l == 1 ? x0 : h->y[l - 1], false);
-                ws[nw].e.done = d->done + l;
-                d->done_target[l] += (unsigned)(((h->ld[l - 1] + 63) / 64) * ((h->ld[l] + 63) / 64));
-                ++nw;
-            }
-            const DpPeers peers = dp_peers(d);
-            for (int l = 1; l < L; ++l) {
-                hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + l, d->done_target[l], peers, d->flags, d->world,
-                                   bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->epoch, d->budget_ticks, d->err, 1u);
-                CKE(hipGetLastError());
-                CKE(dp_reduce_layer(h, l));
-            }
-            CKE(run_wgrads(h->stream, ws, nw, true));
-        } else {
-            // layer 1 (the largest segment, needed first by the next forward) goes out alone; the rest as ONE grouped launch:
-            // its exchange queues behind layer 1's on the comm stream anyway, and one launch + one event replace L-2 of each
-            CKE(launch_wgrad(h, h->stream, 1, B, x0, false));
-            CKE(dp_exchange_layers(h, &one, 1));
-            for (int l = 2; l < L; ++l) { ws[nrest] = prep_wgrad(h, l, B, h->y[l - 1], false); rest[nrest++] = l; }
-            if (nrest) {
-                CKE(run_wgrads(h->stream, ws, nrest, true));
-                CKE(dp_exchange_layers(h, rest, nrest));
-            }
-        }
-    }
-#undef CKE
-    return hipSuccess;
-}
-
-// After the last minibatch of a call: the main stream waits until every layer's weights have been gathered (and
-// therefore every peer has finished reading this rank's gradients), so that stream order again covers everything.
-static hipError_t dp_flush(bp_handle *h)
-{
-    bp_dp *d = h->dp;
-    hipError_t er;
-    for (int l = 1; l < h->L; ++l) {
-        if ((er = dp_wait_weights(h, l, d->epoch)) != hipSuccess) return er;
-        if (h->bf && d->epoch && (er = bf_shadow(h, l)) != hipSuccess) return er;
-    }
-    if ((er = hipEventRecord(d->ev_comm, d->comm)) != hipSuccess) return er;
-    return hipStreamWaitEvent(h->stream, d->ev_comm, 0);
-}
-
-// bp_get_deltas on an attached handle: the momentum state is sharded; pull the peers' slices into the local arena.
-static int dp_gather_deltas(bp_handle *h)
-{
-    bp_dp *d = h->dp;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (rdv_barrier(d->rdv) != 0) return fail(BP_ERR_STATE, g_rdv_err);   // every rank quiescent: slices are final
-    for (int l = 1; l < h->L; ++l) {
-        const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + d->world - 1) / d->world;
-        for (int p = 0; p < d->world; ++p) {
-            if (p == d->rank) continue;
-            const size_t a = per4 * p < cnt4 ? per4 * p : cnt4, b = per4 * (p + 1) < cnt4 ? per4 * (p + 1) : cnt4;
-            if (b <= a) continue;
-            const size_t off = h->g_off[l] + 4 * a;
-            int grid = (int)((b - a + 255) / 256); if (grid > 1024) grid = 1024;
-            hipLaunchKernelGGL(bp_dp_copy, dim3(grid), dim3(256), 0, h->stream, h->deltas + off, d->p_deltas[p] + off, (unsigned long long)(b - a));
-            HIPCHK(hipGetLastError());
-        }
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (rdv_barrier(d->rdv) != 0) return fail(BP_ERR_STATE, g_rdv_err);   // nobody resumes training while a peer still reads
-    return BP_OK;
-}
-
-extern "C" int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibatches)
-{
-    if (!h) return fail(BP_ERR_ARG, "null handle");
-    if (world) *world = h->dp ? h->dp->world : 0;
-    if (rank) *rank = h->dp ? h->dp->rank : 0;
-    if (minibatches) *minibatches = h->dp ? h->dp->epoch : 0;
-    return BP_OK;
-}
-
-extern "C" int bp_dp_peer_info(bp_handle *h, int peer, int *device, char *pci_bus_id, int len, int *transport, int *acquire_mode)
-{
-    if (!h || !h->dp) return fail(BP_ERR_STATE, "bp_dp_peer_info: handle is not attached");
-    if (peer < 0 || peer >= h->dp->world) return fail(BP_ERR_ARG, "bp_dp_peer_info: peer out of range");
-    if (device) *device = h->dp->peer_device[peer];
-    if (pci_bus_id && len > 0) { strncpy(pci_bus_id, h->dp->peer_pci[peer], (size_t)len - 1); pci_bus_id[len - 1] = 0; }
-    if (transport) *transport = h->dp->backend;
-    if (acquire_mode) *acquire_mode = h->dp->acquire_mode;
-    return BP_OK;
-}
-extern "C" int bp_dp_barrier(bp_handle *h)
-{
-    if (!h || !h->dp) return fail(BP_ERR_STATE, "bp_dp_barrier: handle is not attached");
-    return rdv_barrier(h->dp->rdv) == 0 ? BP_OK : fail(BP_ERR_STATE, g_rdv_err);
-}
-extern "C" int bp_dp_allgather(bp_handle *h, const void *mine, size_t bytes, void *all)
-{
-    if (!h || !h->dp || !mine || !all) return fail(BP_ERR_STATE, "bp_dp_allgather: handle is not attached / null argument");
-    return rdv_allgather(h->dp->rdv, mine, bytes, all) == 0 ? BP_OK : fail(BP_ERR_STATE, g_rdv_err);
-}
-
 // ------------------------------------------------------------------ inference / CV
 // Outputs of a whole chunk stay on the device until ONE device-to-host copy at the end (the reference copies and
 // synchronises per bunch and cudaMallocs per call, BP_GPU.cu:699,762-763).
@@ -1896,7 +1213,7 @@ static int get_params(bp_handle *h, float *const *w, float *const *b, bool delta
 {
     if (!h || !w || !b) return fail(BP_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (deltas && h->dp && h->dp->world > 1) { int r = dp_gather_deltas(h); if (r != BP_OK) return r; }
+    if (deltas && dp_gathers_deltas(h)) { int r = dp_gather_deltas(h); if (r != BP_OK) return r; }
     for (int l = 1; l < h->L; ++l) {
         if (!w[l] || !b[l]) return fail(BP_ERR_ARG, "weights[l]/bias[l] null");
         HIPCHK(hipMemcpy2DAsync(w[l], (size_t)h->s[l] * 4, deltas ? h->dW[l] : h->W[l], (size_t)h->ld[l] * 4,
@@ -1909,166 +1226,3 @@ static int get_params(bp_handle *h, float *const *w, float *const *b, bool delta
 extern "C" int bp_get_weights(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, false); }
 extern "C" int bp_get_deltas(bp_handle *h, float *const *w, float *const *b) { return get_params(h, w, b, true); }
 
-
-// ------------------------------------------------------------------ in-step kernel timing + measured peaks
-// bp_train_resident over [first_frame, first_frame + n_bunches*bunchsize) with an event after every launch: the
-// per-class average duration of the step's kernels AS THEY RUN IN THE STEP (same order, same cache state as the
-// timed loop), for the roofline object.  Classes: BP_PROF_* in bp_c_api.h.  fp32 single-device handles only.
-extern "C" int bp_profile_step(bp_handle *h, int first_frame, int n_bunches, float *avg_ms, int *launches_per_step)
-{
-    if (!h || !avg_ms) return fail(BP_ERR_ARG, "bp_profile_step: null argument");
-    if (h->bf || h->dp || h->Bg != h->B) return fail(BP_ERR_STATE, "bp_profile_step: fp32 single-device handles only");
-    if (n_bunches < 1 || first_frame < 0 || (long)first_frame + (long)n_bunches * h->B > h->chunk_frames)
-        return fail(BP_ERR_ARG, "bp_profile_step: frame range outside the resident chunk");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    StepProf prof; prof.used = 0;
-    int rc = BP_OK;
-    if (use_mask(h)) HIPCHK(mask_range(h, first_frame, n_bunches * h->B));
-    h->prof = &prof;
-    hipError_t er = prof_mark(h, -1);                        // origin
-    for (int i = 0; er == hipSuccess && i < n_bunches; ++i) {
-        er = bunch(h, first_frame + i * h->B, true);
-        h->step++;
-    }
-    h->prof = nullptr;
-    if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
-    double sum[BP_PROF_KINDS] = {0}; long cnt[BP_PROF_KINDS] = {0};
-    for (size_t k = 1; er == hipSuccess && k < prof.used; ++k) {
-        float ms = 0.f;
-        er = hipEventElapsedTime(&ms, prof.ev[k - 1], prof.ev[k]);
-        if (prof.kind[k] >= 0 && prof.kind[k] < BP_PROF_KINDS) { sum[prof.kind[k]] += ms; cnt[prof.kind[k]]++; }
-    }
-    for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
-    if (er != hipSuccess) rc = fail(BP_ERR_DEVICE, std::string("bp_profile_step: ") + hipGetErrorString(er));
-    for (int k = 0; k < BP_PROF_KINDS; ++k) {
-        avg_ms[k] = cnt[k] ? (float)(sum[k] / (double)cnt[k]) : 0.f;
-        if (launches_per_step) launches_per_step[k] = (int)(cnt[k] / n_bunches);
-    }
-    return rc;
-}
-
-// Measured peaks of THIS device, taken in the same process as the benchmark: a bare v_mfma_f32_32x32x2_f32 loop
-// (4 independent accumulator chains per wave, 4 waves per SIMD-quad workgroup, no memory traffic) and a float4
-// device-to-device copy of 2 x 1 GiB (read + write bytes counted).
-__global__ __launch_bounds__(256) void bp_peak_mfma_f32(float *sink, int iters, float seed)
-{
-    f32x16 a0, a1, a2, a3;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = seed; a1[r] = seed; a2[r] = seed; a3[r] = seed; }
-    const float x = seed + (float)threadIdx.x * 1e-9f, y = seed * 0.5f;
-    for (int i = 0; i < iters; ++i) {
-        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
-        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
-    if (s == 1.2345e-30f) sink[threadIdx.x] = s;
-}
-// One float4 per thread, no loop, the whole 1 GiB in one grid (tools/copy_probe.hip: 6.27 TB/s plain, 6.59 TB/s with
-// nontemporal accesses on these boxes; the grid-stride form with 4 loads in flight that stood here before reached 4.5-4.8).
-template <bool NT>
-__global__ __launch_bounds__(256) void bp_peak_copy(float4 *dst, const float4 *src, size_t n4)
-{
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const f4v *>(src) + i), reinterpret_cast<f4v *>(dst) + i);
-    else dst[i] = src[i];
-}
-extern "C" int bp_measure_peaks(bp_handle *h, float *mfma_f32_tflops, float *hbm_copy_gbs)
-{
-    if (!h || !mfma_f32_tflops || !hbm_copy_gbs) return fail(BP_ERR_ARG, "bp_measure_peaks: null argument");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    float *sink = nullptr;
-    HIPCHK(hipMalloc((void **)&sink, 4096));
-    const int iters = 4096, wgs = 256 * 8;
-    float ms = 0.f, best = 0.f;
-    for (int rep = 0; rep < 4; ++rep) {
-        HIPCHK(hipEventRecord(a, h->stream));
-        hipLaunchKernelGGL(bp_peak_mfma_f32, dim3(wgs), dim3(256), 0, h->stream, sink, iters, 1.0f);
-        HIPCHK(hipEventRecord(b, h->stream));
-        HIPCHK(hipEventSynchronize(b));
-        HIPCHK(hipEventElapsedTime(&ms, a, b));
-        const float tf = (float)((double)wgs * 4 * iters * 4 * (2.0 * 32 * 32 * 2) / (ms * 1e-3) / 1e12);
-        if (rep > 0 && tf > best) best = tf;
-    }
-    *mfma_f32_tflops = best;
-    (void)hipFree(sink);
-    const size_t bytes = (size_t)1 << 30;
-    float4 *src = nullptr, *dst = nullptr;
-    HIPCHK(hipMalloc((void **)&src, bytes)); HIPCHK(hipMalloc((void **)&dst, bytes));
-    HIPCHK(hipMemsetAsync(src, 1, bytes, h->stream));
-    best = 0.f;
-    for (int rep = 0; rep < 6; ++rep) {
-        HIPCHK(hipEventRecord(a, h->stream));
-        if (rep < 3) hipLaunchKernelGGL(bp_peak_copy<false>, dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, h->stream, dst, src, bytes / 16);
-        else hipLaunchKernelGGL(bp_peak_copy<true>, dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, h->stream, dst, src, bytes / 16);   // plain and nontemporal, best reported
-        HIPCHK(hipEventRecord(b, h->stream));
-        HIPCHK(hipEventSynchronize(b));
-        HIPCHK(hipEventElapsedTime(&ms, a, b));
-        const float gbs = (float)(2.0 * (double)bytes / (ms * 1e-3) / 1e9);
-        if (rep > 0 && gbs > best) best = gbs;
-    }
-    *hbm_copy_gbs = best;
-    (void)hipFree(src); (void)hipFree(dst);
-    HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b));
-    return BP_OK;
-}
-
-// ------------------------------------------------------------------ isolated kernel timing
-extern "C" int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms)
-{
-    if (!h || !avg_ms || iters < 1) return fail(BP_ERR_ARG, "bp_time_kernel: bad argument");
-    if (h->L < 4 && (which == 0 || which == 1 || which == 2))
-        return fail(BP_ERR_ARG, "bp_time_kernel: needs a hidden->hidden layer (numlayers >= 4)");
-    if (h->bf) return fail(BP_ERR_STATE, "bp_time_kernel: fp32 kernels only");
-    if (h->chunk_frames < h->B || h->windows) return fail(BP_ERR_STATE, "bp_time_kernel: no resident stacked chunk");
-    HIPCHK(hipSetDevice(h->cfg.device));
-    const int L = h->L, B = h->B;
-    hipEvent_t a, b;
-    float *scratch_w = nullptr, *scratch_d = nullptr, *scratch_b = nullptr;
-    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    for (int it = -2; it < iters; ++it) {
-        if (it == 0) HIPCHK(hipEventRecord(a, h->stream));
-        hipError_t er = hipSuccess;
-        switch (which) {
-        case 0: er = launch_fwd(h, h->stream, 2, B, h->y[1], nullptr, nullptr, true, 1.0f); break;
-        case 1: er = launch_dgrad(h, h->stream, 3 < L ? 3 : 2, B); break;
-        case 2: case 5: {
-            // wgrad + fused update on scratch copies of W / delta (same traffic, state untouched)
-            const int l = which == 2 ? 2 : 1;
-            const size_t nw = (size_t)h->ld[l - 1] * h->ld[l];
-            if (!scratch_w) {
-                HIPCHK(hipMalloc((void **)&scratch_w, nw * 4)); HIPCHK(hipMalloc((void **)&scratch_d, nw * 4));
-                HIPCHK(hipMalloc((void **)&scratch_b, (size_t)h->ld[l] * 8));
-                HIPCHK(hipMemcpyAsync(scratch_w, h->W[l], nw * 4, hipMemcpyDeviceToDevice, h->stream));
-                HIPCHK(hipMemsetAsync(scratch_d, 0, nw * 4, h->stream));
-                HIPCHK(hipMemsetAsync(scratch_b, 0, (size_t)h->ld[l] * 8, h->stream));
-            }
-            float *W0 = h->W[l], *D0 = h->dW[l], *b0 = h->b[l], *db0 = h->db[l];
-            h->W[l] = scratch_w; h->dW[l] = scratch_d; h->b[l] = scratch_b; h->db[l] = scratch_b + h->ld[l];
-            er = launch_wgrad(h, h->stream, l, B, l == 1 ? h->in : h->y[l - 1], true);
-            h->W[l] = W0; h->dW[l] = D0; h->b[l] = b0; h->db[l] = db0;
-            break;
-        }
-        case 3: er = launch_fwd(h, h->stream, 1, B, h->in, nullptr, nullptr, true, 1.0f); break;
-        case 4: er = launch_fwd(h, h->stream, L - 1, B, h->y[L - 2], h->targ, nullptr, true, 1.0f); break;
-        default: HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b));
-                 return fail(BP_ERR_ARG, "bp_time_kernel: unknown kernel id");
-        }
-        HIPCHK(er);
-    }
-    HIPCHK(hipEventRecord(b, h->stream));
-    HIPCHK(hipEventSynchronize(b));
-    float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, a, b));
-    *avg_ms = ms / iters;
-    if (scratch_w) { (void)hipFree(scratch_w); (void)hipFree(scratch_d); (void)hipFree(scratch_b); }
-    HIPCHK(hipEventDestroy(a)); HIPCHK(hipEventDestroy(b));
-    return BP_OK;
-}

@@ -19,6 +19,13 @@
 #pragma once
 #include "bp_kernels.h"
 
+// memory order of the per-tile count of the data-parallel gradient store (development builds can A/B the relaxed form)
+#if defined(BP_DEV) && defined(BP_DP_TILE_RELAXED)
+#define BP_DP_TILE_ORDER __ATOMIC_RELAXED
+#else
+#define BP_DP_TILE_ORDER __ATOMIC_RELEASE
+#endif
+
 // template <BK, ST, MINWG, K>: K = frames of the bunch (static).  Prefetch distance D = ST-1 tiles.
 template <int N> struct VmWait { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory"); } };
 
@@ -59,18 +66,12 @@ struct WgradDma {
 #pragma unroll
         for (int s = 0; s < RD; ++s) { av[s] = ap[2 * s * BM]; bv[s] = bp[2 * s * BN]; }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(BP_WG_SETPRIO) && BP_WG_SETPRIO     // development A/B: the 4 workgroups of a CU are independent and out of phase (guide T5)
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
             acc[s & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc[s & 1], 0, 0, 0);
             if (s + RD < NK) { av[s + RD] = ap[2 * (s + RD) * BM]; bv[s + RD] = bp[2 * (s + RD) * BN]; }
             __builtin_amdgcn_sched_barrier(0);
         }
-#if defined(BP_WG_SETPRIO) && BP_WG_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     }
     template <int T>
     static __device__ __forceinline__ void iter(const GemmArgs &g, const EpiArgs &e, int m0, int n0, float *smem, int wave, int lane, int tid,
@@ -137,13 +138,14 @@ struct WgradDma {
             if constexpr (STORE) {
                 // data-parallel step: tell the exchange stream that this tile of the layer's gradient segment is complete, WITHOUT a
                 // kernel boundary (one grouped launch for all layers; the exchange of layer 1 starts while the other layers' tiles
-                // still run).  Every storing wave drains its stores, then one lane counts the tile.  No release fence: the gradient
-                // buffer is fine-grained memory, its consumers read it with system-scope loads, and bp_dp_attach's self-test
-                // checks exactly this hand-off on the group's devices before the step relies on it (bp_dp.h).
+                // still run).  Every storing wave drains its stores, the workgroup meets at a barrier, then one lane counts the tile
+                // with a system-scope RELEASE: behind the barrier it is cumulative over the whole workgroup's stores, so a peer that
+                // sees the count (through bp_dp_sync's flag) sees the tile -- by the memory model, not only by the attach-time
+                // self-test, which stays as a cross-check of the platform (bp_dp.h).
                 if (e.done) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_fetch_add(e.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (tid == 0) __hip_atomic_fetch_add(e.done, 1u, BP_DP_TILE_ORDER, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }

@@ -13,11 +13,11 @@
 // SOURCE address: 16-byte slot s of row r holds k-chunk s ^ ((r >> 2) & 3); an MFMA fragment read (ds_read_b128 of one
 // chunk per lane, 32 rows per half-wave) then touches all 64 banks once per 16-lane group.  64x64 tiles, 4 waves of
 // one 32x32 block, 32-frame k-tiles in a 4-stage ring (32 KB => 4 workgroups per CU), three tiles in flight, ONE raw
-// s_barrier per k-tile with an exact counted vmcnt; the W / delta tile is fetched by plain loads issued right behind
-// the LAST operand tile (four-wave form: WgradDmaBf::run, the data-parallel gradient store and the A/B fallback).  The fused update
-// of the single-device step is the SIX-wave form at the end of this file (WgradDmaBf6: two waves own W / delta on their own
-// vmcnt; 64-frame k-tiles in a ring of 3 for bunches of 256 frames and more).  The step is HBM-bound here (20 bytes per parameter: fp32 W and delta read + written, one bf16
-// shadow written); what this kernel buys over bp_gemm_bf16<BEPI_WGRAD_UPDATE> is occupancy (80 VGPRs), no register
+// s_barrier per k-tile with an exact counted vmcnt.  Two kernels share that loop (WgradDmaBf): the data-parallel gradient
+// STORE (four waves; tile and bias gradient go to the flat gradient buffer) and the fused update of the single-device step, the
+// SIX-wave form at the end of this file (WgradDmaBf6: two more waves own W / delta on their own vmcnt; 64-frame k-tiles in a
+// ring of 3 for bunches of 256 frames and more).  The step is HBM-bound here (18 bytes per parameter: fp32 W and delta read +
+// written, one bf16 shadow written); what this buys over bp_gemm_bf16<BEPI_WGRAD_UPDATE> is occupancy (80 VGPRs), no register
 // staging, one launch for all layers instead of one GEMM + one bias kernel per layer.
 #pragma once
 #include "bp_kernels.h"
@@ -35,13 +35,13 @@ enum { BF_WGRAD_MAXP = 8 };
 struct BfWgradMulti { BfWgradProblem p[BF_WGRAD_MAXP]; int first_tile[BF_WGRAD_MAXP + 1]; int n; };
 
 // BKX = 64 (rows of 128 bytes = whole lines per DMA request instead of halves; slot s of row r holds chunk s ^ ((r>>1)&7)), STX = ring length
-template <int KTOT, bool STORE, int BKX = 32, int STX = 4>
+template <int KTOT, int BKX = 32, int STX = 4>
 struct WgradDmaBf {
     static constexpr int BM = 64, BN = 64, BK = BKX, ST = STX, D = ST - 1, NT = KTOT / BK;
     static constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK, STAGE = A_STAGE + B_STAGE;     // halfs
     static constexpr int SMEM = ST * STAGE;                                                    // halfs (32 KB; 48 KB for 64-deep tiles x 3)
     static constexpr int CH = BK / 8, RPP = 512 / BK, NA = BM / RPP / 4;                       // 16-byte chunks per row, rows per 1 KiB piece, pieces per wave and operand
-    static constexpr int NDMA = 2 * NA, NWD = STORE ? 0 : 32;
+    static constexpr int NDMA = 2 * NA;
     static_assert((BK == 32 || BK == 64) && KTOT % BK == 0 && NT > D, "bunch rows");
     static __device__ __forceinline__ int swz(int r) { return BK == 32 ? (r >> 2) & 3 : (r >> 1) & 7; }
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -76,16 +76,14 @@ struct WgradDmaBf {
     }
     template <int T>
     static __device__ __forceinline__ void iter(const BfWgradProblem &g, int m0, int n0, bf16_t *smem, int wave, int lane, int tid, int ra, int rb,
-                                                int kh, int mb, int nb, bool do_bias, float &bsum, f32x16 &acc, EpiPre &pre)
+                                                int kh, bool do_bias, float &bsum, f32x16 &acc)
     {
         if constexpr (T < NT) {
-            // in flight here: tiles T .. min(T+D, NT)-1, plus the 32 W/delta loads once the last tile has been issued
+            // in flight here: tiles T .. min(T+D, NT)-1
             constexpr int tiles_after = (T + D < NT ? D : NT - T) - 1;
-            constexpr bool wd_out = T + D > NT;
-            VmWait<tiles_after * NDMA + (wd_out ? NWD : 0)>::go();
+            VmWait<tiles_after * NDMA>::go();
             __builtin_amdgcn_s_barrier();
             if constexpr (T + D < NT) issue_tile(g, m0, n0, (T + D) * BK, smem, (T + D) % ST, wave, lane);
-            if constexpr (T + D == NT && !STORE) epilogue_fetch<EPI_WGRAD_UPDATE, 0, 16>(g.e, mb, nb, lane, pre);     // behind the last tile
             if (do_bias) {          // column sums of dEdX: row (tid >> 2) of the B tile, one 16-byte chunk per thread (any slot order)
                 // (inline asm: for a plain LDS load next to in-flight LDS-DMA hipcc drains vmcnt(0) first, which would
                 // serialise this workgroup's whole ring; the counted wait above already covers the stage read here)
@@ -100,9 +98,10 @@ struct WgradDmaBf {
                 }
             }
             multiply(smem, T % ST, ra, rb, kh, acc);
-            iter<T + 1>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, mb, nb, do_bias, bsum, acc, pre);
+            iter<T + 1>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, do_bias, bsum, acc);
         }
     }
+    // the data-parallel gradient store: tile and bias gradient into the flat gradient buffer (e.C / e.bias_g)
     static __device__ __forceinline__ void run(const BfWgradProblem &g, int first_block, int stride, bf16_t *smem)
     {
         const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,74 +118,29 @@ struct WgradDmaBf {
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const bool do_bias = tile_m == 0;
             float bsum = 0.f;
-            EpiPre pre;
 #pragma unroll
             for (int t = 0; t < D; ++t) issue_tile(g, m0, n0, t * BK, smem, t, wave, lane);
-            iter<0>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, mb, nb, do_bias, bsum, acc, pre);
+            iter<0>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, do_bias, bsum, acc);
             if (do_bias) {
                 bsum += __shfl_xor(bsum, 1);
                 bsum += __shfl_xor(bsum, 2);
                 const int n = n0 + (tid >> 2);
-                if ((tid & 3) == 0 && n < e.n_limit) {
-                    if constexpr (STORE) {
-                        e.bias_g[n] = bsum;
-                    } else {
-                        const float d = e.mom * e.bias_d[n] - e.c1 * (bsum / e.ndiv + 0.0f * e.bias_w[n]);
-                        e.bias_d[n] = d;
-                        e.bias_w[n] = d + 1.0f * e.bias_w[n];
-                    }
-                }
+                if ((tid & 3) == 0 && n < e.n_limit) e.bias_g[n] = bsum;
             }
-            // ---- epilogue: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block.
-            // Padded rows / columns hold zeros in W, delta and G and stay zero under the update: no predicates.
+            // lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block.  Padded rows / columns
+            // hold zeros in G: no predicates.
             const int n = nb + (lane & 31), rbase = mb + 4 * (lane >> 5);
-            if constexpr (STORE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n] = acc[r];
-            } else {
-                // The bf16 shadow leaves through LDS so that it reaches memory as FULL 128-byte lines: written straight from the
-                // accumulator layout it is 64-byte pieces of lines (round 3 measured 112 us of an 813 us configs[4] step for the
-                // then TWO shadows written that way).  The operand ring is free once every wave has passed its last multiply:
-                // sWb [64 m][72] halfs (144-byte rows).  (The second, transposed shadow of round 3 is gone: the forward reads
-                // this one through the transpose read, bp_bf16.h.)
-                constexpr int LDSH = 72;
-                bf16_t *sWb = smem;
-                __syncthreads();
-                const int ml = wm * 32 + 4 * (lane >> 5), nl = wn * 32 + (lane & 31);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bf16_t hb[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = 4 * q + j;
-                        const size_t i = (size_t)(rbase + 8 * q + j) * e.ldc + n;
-                        const float w = pre.p0[r];
-                        const float d = e.mom * pre.p1[r] - e.c1 * (acc[r] / e.ndiv + e.wc * w);     // kernUpdatedelta
-                        e.aux2[i] = d;
-                        const float wnew = d + 1.0f * w;                                             // kernAccSum
-                        e.C[i] = wnew;
-                        hb[j] = f2bf(wnew);
-                        sWb[(ml + 8 * q + j) * LDSH + nl] = hb[j];
-                    }
-                }
-                __syncthreads();
-                // 8 threads per 128-byte row, 32 rows per pass: Wb rows m0..
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = (tid >> 3) + 32 * i, ch = (tid & 7) * 8;
-                    const uint4 a4 = *reinterpret_cast<const uint4 *>(sWb + row * LDSH + ch);
-                    *reinterpret_cast<uint4 *>(g.Wb + (size_t)(m0 + row) * g.ldwb + n0 + ch) = a4;
-                }
-            }
+            for (int r = 0; r < 16; ++r) e.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * e.ldc + n] = acc[r];
             if (b + stride < g.tiles_m * g.tiles_n) __syncthreads();      // the ring is refilled by the next tile's prologue
         }
     }
 };
 
-template <int KTOT, bool STORE>
-__global__ __launch_bounds__(256, 4) void bp_wgrad_dma_bf16(const BfWgradMulti a)
+template <int KTOT>
+__global__ __launch_bounds__(256, 4) void bp_wgrad_dma_bf16_store(const BfWgradMulti a)
 {
-    using K = WgradDmaBf<KTOT, STORE>;
+    using K = WgradDmaBf<KTOT>;
     __shared__ __attribute__((aligned(16))) bf16_t smem[K::SMEM];
     const int b = blockIdx.x;
     int p = 0;
@@ -209,7 +163,7 @@ __global__ __launch_bounds__(256, 4) void bp_wgrad_dma_bf16(const BfWgradMulti a
 // by the master weights behind them -- forward GEMM 36.9 -> 28.5 us per launch, this launch 326 -> 305 us (same box A/B).
 template <int KTOT, int BKX = 32, int STX = 4>
 struct WgradDmaBf6 {
-    using M = WgradDmaBf<KTOT, true, BKX, STX>;                      // the MFMA waves' loop (STORE flavour: no W/delta traffic in it)
+    using M = WgradDmaBf<KTOT, BKX, STX>;                            // the MFMA waves' loop (no W/delta traffic in it)
     static constexpr int GLD = 68;                         // floats per row of the staged gradient tile [64][68]
     typedef float nt_f4 __attribute__((ext_vector_type(4)));
     static_assert(64 * GLD * 4 <= M::SMEM * 2, "gradient tile fits the ring");
@@ -262,17 +216,16 @@ struct WgradDmaBf6 {
             return;
         }
         // ---- MFMA waves
-        const int wm = wave >> 1, wn = wave & 1, mb = m0 + wm * 32, nb = n0 + wn * 32;
+        const int wm = wave >> 1, wn = wave & 1;
         const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31), kh = lane >> 5;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         const bool do_bias = tile_m == 0;
         float bsum = 0.f;
-        EpiPre pre;
 #pragma unroll
         for (int t = 0; t < M::D; ++t) M::issue_tile(g, m0, n0, t * M::BK, smem, t, wave, lane);
-        M::template iter<0>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, mb, nb, do_bias, bsum, acc, pre);
+        M::template iter<0>(g, m0, n0, smem, wave, lane, tid, ra, rb, kh, do_bias, bsum, acc);
         __syncthreads();
         {   // gradient block -> LDS: lane -> column, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block
             const int nl = wn * 32 + (lane & 31), ml = wm * 32 + 4 * (lane >> 5);
@@ -296,7 +249,7 @@ struct WgradDmaBf6 {
 template <int KTOT, int BKX = 32, int STX = 4>
 __global__ __launch_bounds__(384, 3) void bp_wgrad_dma_bf16_six(const BfWgradMulti a)
 {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[WgradDmaBf<KTOT, true, BKX, STX>::SMEM];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[WgradDmaBf<KTOT, BKX, STX>::SMEM];
     const int b = blockIdx.x;
     int p = 0;
     while (p + 1 < a.n && b >= a.first_tile[p + 1]) ++p;
