@@ -599,8 +599,15 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
         a.first_tile[cnt] = t; a.n = cnt;
         // fused update: six waves (two of them own W / delta), 64-frame k-tiles in a ring of 3 when the bunch has at least 4;
         // data-parallel gradient store: the four-wave loop alone
+#ifdef BP_DEV
+        static const int persist = dev_int("BP_BF16_UPD_PERSIST", 0);          // A/B: workgroups of the persistent form (0 = off)
+#define BF_DMA_PERSIST(K) if (fused && persist > 0) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six_persist<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(persist < t ? persist : t), dim3(384), 0, h->stream, a); else
+#else
+#define BF_DMA_PERSIST(K)
+#endif
 #define BF_DMA_LAUNCH(K)                                                                                             \
-        do { if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(t), dim3(384), 0, h->stream, a); \
+        do { BF_DMA_PERSIST(K)                                                                                       \
+             if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(t), dim3(384), 0, h->stream, a); \
              else hipLaunchKernelGGL((bp_wgrad_dma_bf16_store<K>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
         switch (h->Bp) {
         case 128: BF_DMA_LAUNCH(128); break;
@@ -609,6 +616,7 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
         default: BF_DMA_LAUNCH(1024); break;
         }
 #undef BF_DMA_LAUNCH
+#undef BF_DMA_PERSIST
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return er;
     }

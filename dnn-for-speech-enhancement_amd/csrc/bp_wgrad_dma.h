@@ -19,13 +19,6 @@
 #pragma once
 #include "bp_kernels.h"
 
-// memory order of the per-tile count of the data-parallel gradient store (development builds can A/B the relaxed form)
-#if defined(BP_DEV) && defined(BP_DP_TILE_RELAXED)
-#define BP_DP_TILE_ORDER __ATOMIC_RELAXED
-#else
-#define BP_DP_TILE_ORDER __ATOMIC_RELEASE
-#endif
-
 // template <BK, ST, MINWG, K>: K = frames of the bunch (static).  Prefetch distance D = ST-1 tiles.
 template <int N> struct VmWait { static __device__ __forceinline__ void go() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory"); } };
 
@@ -139,13 +132,14 @@ struct WgradDma {
                 // data-parallel step: tell the exchange stream that this tile of the layer's gradient segment is complete, WITHOUT a
                 // kernel boundary (one grouped launch for all layers; the exchange of layer 1 starts while the other layers' tiles
                 // still run).  Every storing wave drains its stores, the workgroup meets at a barrier, then one lane counts the tile
-                // with a system-scope RELEASE: behind the barrier it is cumulative over the whole workgroup's stores, so a peer that
-                // sees the count (through bp_dp_sync's flag) sees the tile -- by the memory model, not only by the attach-time
-                // self-test, which stays as a cross-check of the platform (bp_dp.h).
+                // (relaxed).  The RELEASE that makes the counted tiles visible outside this device is not paid here but once per layer
+                // and XCD by bp_dp_sync (bp_dp.h), which the count wakes: a system-scope release per TILE (ADVICE r4's first proposal)
+                // was measured at +91 us per C2 step -- 0.3445 vs 0.2533 ms through the exchange path, profiles/r05_dp_world1.txt --
+                // because every one of the 3648 tiles then waits for an L2 write-back request.
                 if (e.done) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_fetch_add(e.done, 1u, BP_DP_TILE_ORDER, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (tid == 0) __hip_atomic_fetch_add(e.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }

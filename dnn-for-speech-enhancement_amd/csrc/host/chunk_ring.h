@@ -145,6 +145,21 @@ private:
     struct Slot { std::atomic<int> tables_seq, converted, ready_seq, consumed; int n_samples, n_frames, n_nat; };
     struct Hdr { std::atomic<int> abort, err_set; std::atomic<int> pid[8]; Slot slot[2]; char err[256]; };
     float *slot_fea(int s) const { return (float *)(base_ + 4096 + (size_t)s * slot_bytes_); }
+    // A rank is gone when its pid no longer exists -- or exists only as a ZOMBIE: the ranks are children of rank 0, which
+    // reaps them at the very end, so a crashed child stays in the process table (kill(pid, 0) still succeeds) until then.
+    static bool pid_gone(int pid)
+    {
+        if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) return true;
+        char path[64], buf[512];
+        snprintf(path, sizeof path, "/proc/%d/stat", pid);
+        FILE *f = fopen(path, "r");
+        if (!f) return false;                                    // (no procfs: fall back to the time-out)
+        const size_t n = fread(buf, 1, sizeof buf - 1, f);
+        fclose(f);
+        buf[n] = 0;
+        const char *p = strrchr(buf, ')');                      // "pid (comm) S ...": the state letter follows the last ')'
+        return p && p[1] == ' ' && (p[2] == 'Z' || p[2] == 'X');
+    }
     template <class F> bool wait(F cond)
     {
         struct timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -153,7 +168,7 @@ private:
             if ((spins & 1023) == 1023) {                        // every ~0.2 s
                 for (int r = 0; r < world_ && r < 8; ++r) {      // a registered peer that no longer exists: nobody will wake us
                     const int pid = hdr_->pid[r].load();
-                    if (pid > 0 && kill((pid_t)pid, 0) != 0 && errno == ESRCH) { fail("chunk ring: rank " + std::to_string(r) + " (process " + std::to_string(pid) + ") is gone"); return false; }
+                    if (pid > 0 && pid_gone(pid)) { fail("chunk ring: rank " + std::to_string(r) + " (process " + std::to_string(pid) + ") is gone"); return false; }
                 }
                 struct timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
                 if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s_) { fail("chunk ring: timed out waiting for a peer"); return false; }

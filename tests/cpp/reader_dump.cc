@@ -65,12 +65,16 @@ int main(int argc, char **argv)
         int rank = 0;
         std::vector<pid_t> kids;
         for (int k = 1; k < world; ++k) { const pid_t c = fork(); if (c == 0) { rank = k; kids.clear(); break; } kids.push_back(c); }
+        ring.register_rank(rank);
+        // RING_DIE_RANK=k: rank k dies right here and stays a zombie (its parent, rank 0, only reaps at the end) -- the others
+        // must notice within seconds instead of waiting out the ring's time budget (tests/test_pfile_reader.py)
+        if (getenv("RING_DIE_RANK") && rank != 0 && atoi(getenv("RING_DIE_RANK")) == rank) _exit(3);
         std::thread helper([&] { for (int i = 0; i < nch; ++i) if (!ring.produce(r, p, i, i, true, rank)) return; });
         FILE *o = fopen((std::string(argv[16]) + ".rank" + std::to_string(rank)).c_str(), "wb");
         const int D = rc.fea_dim, ctx = rc.fea_context, OD = rc.out_dim, s0 = rc.input_dim;
         for (int i = 0; i < nch; ++i) {
             bp::ChunkRing::View v;
-            if (!ring.acquire(i, v)) return 5;
+            if (!ring.acquire(i, v)) { helper.join(); if (rank != 0) _exit(5); return 5; }
             const std::vector<int> rows = bp::shard_rows(v.n_samples, Bg, world, rank);
             const int n = (int)rows.size();
             fwrite(&n, 4, 1, o);

@@ -102,6 +102,24 @@ def test_inference_planner_emits_every_window_once(tmp_path, dump_exe, D, ctx, c
     assert np.array_equal(got, exp)
 
 
+def test_ring_notices_a_crashed_child_rank_while_it_is_still_a_zombie(tmp_path, dump_exe):
+    """the ranks are children of rank 0, which reaps them only at the very end -- a crashed rank therefore stays
+    in the process table as a zombie and kill(pid, 0) keeps succeeding.  The ring must still report it within seconds
+    (the state letter in /proc/<pid>/stat), not after its 150 s time budget."""
+    import time
+    rs = np.random.default_rng(5)
+    D, ctx, OD, lens = 5, 1, 4, [6, 9, 3, 12, 5, 30, 8]
+    n = sum(lens)
+    fp, tp, npth, pref = (str(tmp_path / x) for x in ("f.pfile", "t.pfile", "n.norm", "ring"))
+    PU.write_pfile(fp, lens, rs.normal(size=(n, D)).astype(np.float32)); PU.write_pfile(tp, lens, rs.normal(size=(n, OD)).astype(np.float32))
+    PU.write_norm(npth, np.zeros(D, np.float32), np.ones(D, np.float32))
+    args = [dump_exe, "ring", fp, tp, npth, str(D), str(ctx), "0", str(OD), "24", str(D * ctx), "0", str(len(lens) - 1), "77", "3", "6", pref]
+    t0 = time.time()
+    r = subprocess.run(args, env=dict(os.environ, RING_DIE_RANK="2"), timeout=120)
+    assert r.returncode == 5, r.returncode                 # acquire() failed on rank 0 (a clean run returns 0)
+    assert time.time() - t0 < 30.0
+
+
 @pytest.mark.parametrize("world,Bg", [(2, 4), (3, 6), (8, 8)])
 @pytest.mark.parametrize("D,ctx,toff,OD,cache,nat,lens", [
     (6, 3, 1, 3, 16, True, [10, 2, 7, 15, 4, 9, 22, 13]),         # cuts mid-sentence, short sentence, noise-aware rows
