@@ -12,8 +12,9 @@ per GPU per step, lrate 1, momentum 0.5, synthetic N(0,1) frames resident in HBM
 device), Glorot*0.5 weights.  A step = forward + backward + momentum update of one bunch
 (train_bunch_single, BP_GPU.cu:484-673).  For N>1 the global bunch is N*256 frames and the
 gradient exchange is the LIBRARY's own (bp_dp_attach: hipIpc peer reduce-scatter + sharded fused
-update + all-gather, include/bp_c_api.h; --exchange rccl selects RCCL reduce-scatter/all-gather as the transport of
-the same step) -- the barrier around the timed region and the max over ranks go through the same group's shared-memory
+update + all-gather, include/bp_c_api.h) AND the same step over RCCL reduce-scatter/all-gather, timed back to back in the
+one run: the line carries `exchange: {native, rccl, chosen}` and its value is the faster transport (--exchange native|rccl
+times one only) -- the barrier around the timed region and the max over ranks go through the same group's shared-memory
 rendezvous (bp_dp_barrier / bp_dp_allgather); no torch.distributed, no gloo.  The line lists what every rank attached
 to (device ordinal, PCI bus id).
 
@@ -90,10 +91,46 @@ def cpu_baseline(W, b, budget_s=12.0, max_steps=64):
                      "(cache-blocked AVX GEMMs, OpenMP, %d threads = fastest of the probe %s on %d visible CPUs), %.1f s"
                      % (n, cores, {k: round(v, 3) for k, v in probe.items()}, ncpu, dt)}
     try:
+        res["c1"] = cpu_baseline_c1(O, cores)
+    except Exception as e:
+        res["c1"] = {"error": str(e)[:200]}
+    try:
         res["torch_cpu_not_the_reference"] = torch_cpu_line(W, b, budget_s=min(6.0, budget_s / 2))
     except Exception as e:                   # a labelled extra, never fatal
         res["torch_cpu_not_the_reference"] = {"error": str(e)[:200]}
     return res
+
+
+C1_LAYERS, C1_BUNCH = [257, 512, 257], 128     # BASELINE.json configs[0]: 1x512 Sigmoid, 257-bin single-frame input, 128-frame minibatches
+
+
+def cpu_baseline_c1(O, cores, frames=36000, budget_s=4.0):
+    """SURVEY 8(d) "CPU baseline ... frames/s for C1 (full)": the oracle on the C1 shape over a whole synthetic training
+    pass the size of c1_end_to_end's Pfile pair (120 sentences x 300 frames = 281 minibatches of 128, Sigmoid, classic
+    momentum, no dropout), host wall clock around the pass as the reference times its passes (BPtrain.cc:25-26,91-92)."""
+    import dnnse_amd
+    W, b = dnnse_amd.glorot_net(C1_LAYERS, seed=1, beta=0.5)
+    rng = np.random.default_rng(20260927)
+    nb = frames // C1_BUNCH
+    x = rng.standard_normal((nb * C1_BUNCH, C1_LAYERS[0]), dtype=np.float32)
+    t = rng.standard_normal((nb * C1_BUNCH, C1_LAYERS[-1]), dtype=np.float32)
+    best = None
+    for nt in sorted({1, min(cores, 4), cores}):           # a 0.26 M-parameter net: fewer threads can be faster than the C2 choice
+        O.set_threads(nt)
+        o = O.Oracle(C1_LAYERS, C1_BUNCH, 0.01, 0.5, 0.0, W, b, activation=1, momentum_rule=1)
+        o.train_bunch(x[:C1_BUNCH], t[:C1_BUNCH])
+        t0 = time.perf_counter()
+        done = 0
+        while done < nb and time.perf_counter() - t0 < budget_s:
+            o.train_bunch(x[done * C1_BUNCH:(done + 1) * C1_BUNCH], t[done * C1_BUNCH:(done + 1) * C1_BUNCH], gen_masks=False)
+            done += 1
+        dt = time.perf_counter() - t0
+        if best is None or done * C1_BUNCH / dt > best["value"]:
+            best = {"value": done * C1_BUNCH / dt, "unit": "frames/s", "cores": nt, "kind": "port",
+                    "sample": "%d of %d minibatches (128 frames, 257->512->257 Sigmoid, classic momentum) of one synthetic C1 training pass, "
+                              "oracle/bp_oracle.c on %d threads, %.2f s" % (done, nb, nt, dt)}
+    O.set_threads(cores)
+    return best
 
 
 def torch_cpu_line(W, b, budget_s=6.0):
@@ -183,7 +220,7 @@ def c5_line(dnnse_amd, dev, steps=40):
     # HBM-side bytes of the step from the committed PMC pass (tools/profile_r04.sh): every kernel of one step summed
     traffic, tstamp = None, None
     try:
-        c5_file = next(f for f in ("r04_c5_pmc_hbm_traffic.json", "r03_c5_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        c5_file = next(f for f in ("r05_c5_pmc_hbm_traffic.json", "r04_c5_pmc_hbm_traffic.json", "r03_c5_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
         pm = json.load(open(os.path.join(ROOT, "profiles", c5_file)))
         tot, steps_prof = 0.0, None
         for k, v in pm["kernels"].items():
@@ -331,14 +368,16 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--prewarm-s", type=float, default=1.5, help="seconds of real untimed training steps before the warm-up")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the C5 line and the measured peaks")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C5 line, the measured peaks and the live counter passes")
     ap.add_argument("--sustained-s", type=float, default=4.0, help="seconds of the additional sustained-rate measurement (0 = skip)")
     ap.add_argument("--chunk", type=int, default=CHUNK)
-    ap.add_argument("--exchange", choices=["native", "rccl"], default="native",
-                    help="transport of the data-parallel exchange (N > 1): the library's peer kernels, or RCCL reduce-scatter/all-gather")
+    ap.add_argument("--exchange", choices=["both", "native", "rccl"], default="both",
+                    help="transport of the data-parallel exchange (N > 1): the library's peer kernels, RCCL reduce-scatter/all-gather, or "
+                         "(default) BOTH timed back to back in this one run, the faster one being the line's value")
     ap.add_argument("--force-dp", action="store_true", help="run the exchange path at N = 1 (world-1 group)")
     ap.add_argument("--launch-check", action="store_true",
-                    help="only launch the N ranks, let them meet through the rendezvous and report (no GPU work; CPU-testable)")
+                    help="only launch the N ranks, let them meet through the rendezvous and walk the transport-selection flow with "
+                         "stand-in timings (no GPU work; CPU-testable)")
     return ap.parse_args()
 
 
@@ -363,6 +402,103 @@ def launch_ranks(args):
         sys.exit(1)
 
 
+def run_exchanges(plan, attach, detach, timed, group_failed):
+    """The N > 1 flow: every transport in `plan` is attached AS A GROUP (a failure seen by one rank alone -- a timeout, a
+    self-test verdict -- is all-gathered first, so the ranks always agree on what runs next: ADVICE r3), timed, detached.
+    Returns ({transport: timing dict | {"error": ...}}, chosen transport or None).  The callbacks are the GPU-side pieces;
+    --launch-check passes stand-ins, which is how this control flow is covered on the CPU (tests/test_bench_host.py)."""
+    out = {}
+    for tr in plan:
+        err = attach(tr)                                  # None, or this rank's error text
+        n_failed = group_failed(tr, err)
+        if n_failed:
+            if err is None:
+                detach(tr, broken=True)                   # attached here, but a peer was not: leave that group
+            out[tr] = {"error": "attach failed on %d rank(s): %s" % (int(n_failed), err or "on a peer")}
+            continue
+        out[tr] = timed(tr)
+        detach(tr, broken=False)
+    ok = {k: v for k, v in out.items() if "ms_per_step" in v}
+    chosen = min(ok, key=lambda k: ok[k]["ms_per_step"]) if ok else None
+    return out, chosen
+
+
+def live_pmc(counters, timeout_s=150.0):
+    """One `rocprofv3 --pmc <counters>` pass over a short run of THIS script (C2 headline steps, no extras), on this box, now:
+    {"<kernel> grid=<n>": {counter: median over launches}} or None.  Separate passes per counter set and no tracing next to
+    --pmc, as MI355X_MICROARCH.md prescribes."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", td, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                                                 "--steps", "10", "--warmup", "5", "--no-cpu-baseline", "--no-extras", "--prewarm-s", "0",
+                                                 "--sustained-s", "0", "--chunk", "5120"]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["TMPDIR"] = "/tmp"
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        except Exception:
+            return None
+        acc = {}
+        for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                k = "%s grid=%s" % (r["Kernel_Name"].split("(")[0], r.get("Grid_Size", "?"))
+                acc.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    return {k: {c: statistics.median(v) for c, v in cs.items()} for k, cs in acc.items()} or None
+
+
+def _pick(pmc, pred):
+    for k, v in (pmc or {}).items():
+        if pred(k):
+            return k, v
+    return None, None
+
+
+def live_counters():
+    """HBM-side traffic of the dominant launch and counter-based MFMA utilisation, measured in THIS run:
+    three short rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES + SQ_BUSY_CU_CYCLES)."""
+    is_wgrad = lambda k: k.startswith("void bp_wgrad_dma<16, 4, 4, 256, false>")          # noqa: E731
+    is_hidden = lambda k: k.startswith("void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>")   # noqa: E731  (TAG 0 = layers 2..L-2)
+    out = {}
+    fe, wr = live_pmc(["FETCH_SIZE"]), live_pmc(["WRITE_SIZE"])
+    kf, vf = _pick(fe, is_wgrad)
+    kw, vw = _pick(wr, is_wgrad)
+    if vf and vw and "FETCH_SIZE" in vf and "WRITE_SIZE" in vw:
+        out["traffic_bytes"] = (2.0 * vf["FETCH_SIZE"] + vw["WRITE_SIZE"]) * 1024.0       # KB units; FETCH doubled (gfx950 note in the guide)
+        out["traffic_detail"] = {"kernel": kf, "FETCH_SIZE_KB_median": vf["FETCH_SIZE"], "WRITE_SIZE_KB_median": vw["WRITE_SIZE"],
+                                 "how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 10 --warmup 5 --no-extras` "
+                                        "run by this process on this box; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies wide reads at half)"}
+    sq = live_pmc(["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"])
+    util = {}
+    for name, pred in (("hidden_fwd_2048x2048", is_hidden), ("wgrad_update_grouped", is_wgrad)):
+        k, v = _pick(sq, pred)
+        if v and v.get("SQ_BUSY_CU_CYCLES"):
+            util[name] = {"kernel": k, "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * v["SQ_BUSY_CU_CYCLES"]),
+                          "SQ_VALU_MFMA_BUSY_CYCLES": v["SQ_VALU_MFMA_BUSY_CYCLES"], "SQ_BUSY_CU_CYCLES": v["SQ_BUSY_CU_CYCLES"]}
+    if util:
+        out["mfma_util"] = util
+        out["mfma_util_how"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): the fraction of SIMD-cycles of BUSY CUs with an MFMA in "
+                                "flight (rocprofv3's derived MfmaUtil divides by GRBM_GUI_ACTIVE, which under PMC serialisation includes dispatch idle)")
+    return out
+
+
+def committed_mfma_util():
+    """profiles/r05_mfma_util.json (tools/pmc_sq_summary.py): the same ratio from the committed SQ pass, with its source stamp."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r05_mfma_util.json")))
+        return {"source": "profiles/r05_mfma_util.json", "sources_sha": j.get("sources_sha"),
+                "matches_current_kernel_sources": j.get("sources_sha") == kernel_source_stamp(), "kernels": j.get("kernels")}
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -381,13 +517,36 @@ def main():
 
     import dnnse_amd
 
+    dp = world > 1 or args.force_dp or os.environ.get("BENCH_FORCE_DP") == "1"
+    plan = (["native", "rccl"] if args.exchange == "both" else [args.exchange]) if world > 1 else (["native" if args.exchange == "both" else args.exchange] if dp else [])
+
+    def group_failed(tr, err):
+        """how many ranks failed to attach `tr` (every rank gets the same answer)"""
+        if world == 1:
+            return 1 if err else 0
+        rv = dnnse_amd.Rendezvous("%s-verdict-%s" % (key, tr), world, rank, timeout_s=120.0)
+        n = sum(rv.allgather_f64(1.0 if err else 0.0))
+        rv.close()
+        return n
+
     if args.launch_check:
         rv = dnnse_amd.Rendezvous(key + "-lc", world, rank, timeout_s=60.0)
         pids = rv.allgather_f64(float(os.getpid()))
         rv.barrier()
+        # the transport-selection flow with stand-ins for the GPU side: BENCH_FAKE_FAIL="native:1" makes rank 1's native attach
+        # fail, BENCH_FAKE_MS="native:0.31,rccl:0.29" are the stand-in step times
+        fail_spec = dict(x.split(":") for x in os.environ.get("BENCH_FAKE_FAIL", "").split(",") if ":" in x)
+        ms_spec = {k: float(v) for k, v in (x.split(":") for x in os.environ.get("BENCH_FAKE_MS", "native:0.30,rccl:0.35").split(",") if ":" in x)}
+        log = []
+        ex, chosen = run_exchanges(plan,
+                                   attach=lambda tr: ("stand-in failure" if fail_spec.get(tr) == str(rank) else None),
+                                   detach=lambda tr, broken: log.append(("detach", tr, broken)),
+                                   timed=lambda tr: {"ms_per_step": ms_spec.get(tr, 1.0), "steps": args.steps},
+                                   group_failed=group_failed)
         if rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": list(range(world)), "pids": [int(p) for p in pids],
-                              "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+                              "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
+                              "exchange": dict(ex, chosen=chosen), "detaches": log}), flush=True)
         rv.close()
         return
 
@@ -400,147 +559,149 @@ def main():
     W, b = dnnse_amd.glorot_net(LAYERS, seed=1, beta=0.5)    # Gen_rand_net flag=1, beta=0.5 recipe
     chunk = max(BUNCH, (args.chunk // BUNCH) * BUNCH)
     kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=20260927, device=dev, max_chunk_frames=chunk)
-    dp = world > 1 or args.force_dp or os.environ.get("BENCH_FORCE_DP") == "1"
     if dp:
         kw.update(global_bunchsize=BUNCH * world, rank_frame_offset=rank * BUNCH)
     g = dnnse_amd.BP_GPU(world, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, **kw)
-    rank_table = None
-    exchange_used, exchange_note = args.exchange, None
-    if dp:
-        # The native exchange checks its memory-model assumptions on the group's real devices at attach and refuses to run when
-        # they do not hold.  Rather than produce no number, the group then falls back to the RCCL transport of the same step and
-        # says so in the line -- but only TOGETHER: every rank's verdict is all-gathered over a host-only rendezvous first
-        # (a failure seen by one rank alone, e.g. a timeout, must not send the ranks to different keys).
-        err = None
-        try:
-            g.dp_attach(world, rank, key, transport=1 if args.exchange == "rccl" else 0)
-        except dnnse_amd.BPError as e:
-            err = str(e)[:200]
-        if world > 1:
-            rv = dnnse_amd.Rendezvous(key + "-verdict", world, rank, timeout_s=120.0)
-            n_failed = sum(rv.allgather_f64(1.0 if err else 0.0))
-            rv.close()
-        else:
-            n_failed = 1 if err else 0
-        if n_failed:
-            if args.exchange != "native" or world == 1:
-                raise dnnse_amd.BPError(err or "a peer rank failed to attach")
-            if err is None:
-                try:
-                    g.dp_detach()                               # attached here, but a peer was not: leave that group
-                except dnnse_amd.BPError:
-                    pass                                        # (its closing barrier cannot complete without that peer)
-            exchange_used = "rccl"
-            exchange_note = "native attach failed on %d of %d ranks (%s); the group fell back to the RCCL transport" % (int(n_failed), world, err or "on a peer")
-            g.dp_attach(world, rank, key + "-rccl", transport=1)
-        # what each rank attached to, as the library saw it: a reader can check N ranks on N devices
-        rank_table = []
-        for p in range(world):
-            pdev, pci, tr, aq = g.dp_peer_info(p)
-            rank_table.append({"rank": p, "device": pdev, "pci_bus_id": pci})
-        dp_world, dp_rank, _ = g.dp_info()
-        assert dp_world == world and dp_rank == rank
     g.fill_chunk_synthetic(chunk, 20260927 + rank)            # each rank holds its own shard of every bunch
     g.sync()
     nb_chunk = chunk // BUNCH
+    state = {"pos": 0, "attached": False}
 
     def barrier():
         g.sync()
         torch.cuda.synchronize(dev)
-        if dp:
+        if state["attached"]:
             g.dp_barrier()                                    # host barrier of the group's rendezvous block
 
     def max_over_ranks(v):
-        return max(g.dp_allgather_f64(v, world)) if dp else v
+        return max(g.dp_allgather_f64(v, world)) if state["attached"] else v
 
-    def run(nsteps, pos):
-        done = 0
+    def run(nsteps):
+        done, pos = 0, state["pos"]
         while done < nsteps:
             k = min(nsteps - done, nb_chunk - pos)
             g.train_resident(pos * BUNCH, k * BUNCH)
             done += k
             pos = (pos + k) % nb_chunk
-        return pos
+        state["pos"] = pos
 
-    # ---- untimed pre-warm: real steps, same work as the timed region (every rank the same count)
-    pos, prewarm_steps, t0 = 0, 0, time.perf_counter()
-    if args.prewarm_s > 0:
-        pos = run(200, pos); g.sync(); prewarm_steps = 200
-        per = (time.perf_counter() - t0) / 200
-        extra = int(max_over_ranks(float(int(max(0.0, args.prewarm_s - (time.perf_counter() - t0)) / per))))   # same number of exchanges on every rank
-        if extra > 0:
-            pos = run(extra, pos); g.sync(); prewarm_steps += extra
-    prewarm_s = time.perf_counter() - t0
-    pos = run(args.warmup, pos)
-    barrier()
-    t0 = time.perf_counter()
-    pos = run(args.steps, pos)
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    def timed(tr=None):
+        """untimed pre-warm (real steps, the same count on every rank), W warm-up steps, EXACTLY K timed steps between barriers"""
+        t0, prewarm_steps = time.perf_counter(), 0
+        if args.prewarm_s > 0:
+            run(200); g.sync(); prewarm_steps = 200
+            per = (time.perf_counter() - t0) / 200
+            extra = int(max_over_ranks(float(int(max(0.0, args.prewarm_s - (time.perf_counter() - t0)) / per))))
+            if extra > 0:
+                run(extra); g.sync(); prewarm_steps += extra
+        prewarm_s = time.perf_counter() - t0
+        run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        r = {"ms_per_step": 1e3 * dt / args.steps, "value": args.steps * BUNCH * world / dt, "unit": "frames/s", "steps": args.steps,
+             "prewarm_s": prewarm_s, "prewarm_steps": prewarm_steps, "dt": dt}
+        if tr is not None:
+            # what each rank attached to, as the library saw it: a reader can check N ranks on N devices
+            table = []
+            for p in range(world):
+                pdev, pci, _tr, aq = g.dp_peer_info(p)
+                table.append({"rank": p, "device": pdev, "pci_bus_id": pci})
+            r.update(ranks=table, distinct_devices=len(set(x["pci_bus_id"] for x in table)), dp_acquire_mode=g.dp_peer_info(0)[3])
+            dp_world, dp_rank, _ = g.dp_info()
+            assert dp_world == world and dp_rank == rank
+        # ---- sustained rate (an extra field, not `value`): the same steps for --sustained-s seconds, so that clocks, power and
+        # temperature are at their steady state -- and so that whoever samples the GPU's busy counter during this run sees it
+        if args.sustained_s > 0 and not args.no_extras:
+            n_sus = int(max_over_ranks(float(max(1, int(args.sustained_s / (dt / args.steps))))))      # same count on every rank
+            barrier()
+            t1 = time.perf_counter()
+            run(n_sus)
+            barrier()
+            dt_s = max_over_ranks(time.perf_counter() - t1)
+            r["sustained"] = {"seconds": dt_s, "steps": n_sus, "value": n_sus * BUNCH * world / dt_s, "unit": "frames/s", "ms_per_step": 1e3 * dt_s / n_sus}
+        return r
 
-    frames = args.steps * BUNCH * world
-    value = frames / dt
-    # ---- sustained rate (an extra field, not `value`): the same steps for --sustained-s seconds, so that clocks, power and
-    # temperature are at their steady state -- and so that whoever samples the GPU's busy counter during this run sees it
-    sustained = None
-    if args.sustained_s > 0 and not args.no_extras:
-        n_sus = int(max_over_ranks(float(max(1, int(args.sustained_s / (dt / args.steps))))))      # same count on every rank
-        barrier()
-        t1 = time.perf_counter()
-        pos = run(n_sus, pos)
-        barrier()
-        dt_s = max_over_ranks(time.perf_counter() - t1)
-        sustained = {"seconds": dt_s, "steps": n_sus, "value": n_sus * BUNCH * world / dt_s, "unit": "frames/s",
-                     "ms_per_step": 1e3 * dt_s / n_sus}
+    def attach(tr):
+        # The native exchange checks its memory-model assumptions on the group's real devices at attach and refuses to run when they
+        # do not hold; RCCL may be missing or refuse the topology.  Either is reported in the line, never fatal while one transport works.
+        try:
+            g.dp_attach(world, rank, "%s-%s" % (key, tr), transport=1 if tr == "rccl" else 0)
+            state["attached"] = True
+            return None
+        except dnnse_amd.BPError as e:
+            return str(e)[:200]
+
+    def detach(tr, broken):
+        state["attached"] = False
+        try:
+            g.dp_detach()
+        except dnnse_amd.BPError:
+            if not broken:                                    # (a broken group's closing barrier cannot complete: expected)
+                raise
+
+    exchange, chosen = None, None
+    if dp:
+        exchange, chosen = run_exchanges(plan, attach, detach, timed, group_failed)
+        if chosen is None:
+            raise dnnse_amd.BPError("no data-parallel transport could be attached: %s" % json.dumps(exchange))
+        head = exchange[chosen]
+    else:
+        head = timed(None)
+
+    value = head["value"]
     res = {
         "metric": "training frames/sec (257x11 input, 3x2048 DNN)", "value": value, "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "prewarm_s": prewarm_s, "prewarm_steps": prewarm_steps, "sustained": sustained,
+        "prewarm_s": head["prewarm_s"], "prewarm_steps": head["prewarm_steps"], "sustained": head.get("sustained"),
         "config": {"workload": "C2: 2827->2048->2048->2048->257 ReLU+dropout(0.1/0.2), fp32, %d frames/GPU/step "
                                "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
                                % (BUNCH, BUNCH * world, chunk),
                    "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world,
-                   "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if exchange_used == "rccl" else
+                   "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if chosen == "rccl" else
                                  "in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)") if dp else "none"),
                    "launcher": "self (bench.py forked its ranks)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else
                                ("torch.distributed.run" if world > 1 else "single process")},
     }
-    if rank_table is not None:
-        res["ranks"] = rank_table
-        res["distinct_devices"] = len(set(r["pci_bus_id"] for r in rank_table))
-        res["dp_acquire_mode"] = g.dp_peer_info(0)[3]
-        if exchange_note:
-            res["exchange_note"] = exchange_note
+    if dp:
+        # north_star names RCCL; the library's default is its own peer kernels: ONE run answers which is faster here
+        res["exchange"] = {k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "value", "steps", "error", "dp_acquire_mode", "sustained")})
+                           for k, v in exchange.items()}
+        res["exchange"]["chosen"] = chosen
+        res["exchange"]["note"] = "every transport listed was attached by the whole group and timed with the same protocol in this run; value = the faster one"
+        res["ranks"] = head["ranks"]
+        res["distinct_devices"] = head["distinct_devices"]
+        res["dp_acquire_mode"] = head["dp_acquire_mode"]
     if rank == 0:
         res["step_frac_of_mfma_peak"] = flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF
-    if dp:
-        g.dp_detach()
     if rank == 0 and not dp:
         # ---- roofline of the TIME-DOMINANT kernel: the grouped wgrad + fused momentum update of all layers
         # (bp_wgrad_dma<16,4,4,256>, LDS-DMA staged, one grouped launch per step, ~35 % of the step).  achieved = algorithmic FLOPs per launch (2*B*P: every layer's G = y^T.dEdX) / its average duration
         # INSIDE the step, measured live with HIP events on the launch stream (bp_profile_step: an event after every
         # launch of 100 real training steps).  The rocprofv3 --kernel-trace --stats summary of this same command is
         # committed under profiles/ (its average for that kernel is the cross-check).
-        prof = g.profile_step(0, 100)
+        prof = g.profile_step(0, min(100, nb_chunk))
         wg_ms = prof["wgrad_update_grouped"][0]
         wg_fl = wgrad_flops_per_step(LAYERS, BUNCH)
         ach = wg_fl / (wg_ms * 1e-3) / 1e12
         P = n_params(LAYERS)
         # algorithmic bytes of that launch: W and delta read + written (16P) + every layer's activations and dEdX read once
         alg_bytes = 16.0 * P + 4.0 * BUNCH * (sum(LAYERS[:-1]) + sum(LAYERS[1:]))
-        # HBM-side bytes of that launch: NOT measured in this run (PMC collection needs its own rocprofv3 passes) but read from
-        # the committed pass of tools/profile_r04.sh, stamped with the kernel sources it was taken on
+        # HBM-side bytes of that launch from the committed PMC pass (tools/profile_r05.sh), stamped with the kernel sources it was
+        # taken on; replaced further down by THIS run's own counter passes when they succeed
         traffic, tstamp = None, None
-        for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json"):
             traffic, tstamp = profiled_traffic(name, lambda k: "bp_wgrad_dma" in k and "bf16" not in k and "grid=" in k and int(k.split("grid=")[1]) > 500000)
             if traffic is not None:
                 break
         # cross-check against the committed rocprofv3 --kernel-trace --stats summary of this same command
-        rk_ms = None
+        rk_ms, rk_file = None, None
         try:
             import csv
-            rk_file = next(f for f in ("r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv", "r02_bench_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            rk_file = next(f for f in ("r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", rk_file))):
                 if row["Name"].startswith("void bp_wgrad_dma<16, 4, 4, 256") and "true" not in row["Name"]:     # (the fused-update form)
                     rk_ms = float(row["AverageNs"]) * 1e-6
@@ -565,6 +726,13 @@ def main():
                 "fwd_l1_2827x2048": 4.0 * (LAYERS[0] * LAYERS[1] + BUNCH * (LAYERS[0] + LAYERS[1])) / (prof["fwd_l1"][0] * 1e-3) / 1e9,
                 "fwd_out_2048x257": 4.0 * (LAYERS[-2] * LAYERS[-1] + BUNCH * (LAYERS[-2] + LAYERS[-1])) / (prof["fwd_out"][0] * 1e-3) / 1e9},
         }
+        cm = committed_mfma_util()
+        if cm:
+            res["roofline"]["mfma_util_committed"] = cm
+            hk = next((v for k, v in (cm.get("kernels") or {}).items() if k.startswith("void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>")), None)
+            if hk:
+                res["roofline"]["hidden_fwd_2048x2048"]["mfma_busy_frac"] = hk.get("mfma_busy_frac")
+                res["roofline"]["hidden_fwd_2048x2048"]["mfma_busy_frac_source"] = "profiles/r05_mfma_util.json"
         if not args.no_extras:
             # north_star's GEMM once more from BACK-TO-BACK launches of the same kernel (bp_time_kernel: no event between the
             # launches, so no serialised dispatch in the figure): the number to hold against ">= 60 %"
@@ -585,6 +753,22 @@ def main():
                                                 "note": "bare v_mfma_f32_32x32x2_f32 loop and 1 GiB float4 copy, this device, this process"}
     g.close()
     if rank == 0 and not dp and not args.no_extras:
+        # ---- THIS run's own counter passes (the handle is closed: the child processes have the GPU to themselves)
+        try:
+            lc = live_counters()
+        except Exception as e:
+            lc = {"error": str(e)[:200]}
+        if lc.get("traffic_bytes"):
+            res["roofline"]["traffic_committed"] = {"traffic": res["roofline"]["traffic"], "traffic_stamp": res["roofline"]["traffic_stamp"]}
+            res["roofline"]["traffic"] = lc["traffic_bytes"]
+            res["roofline"]["traffic_stamp"] = dict(lc["traffic_detail"], measured_in_this_run=True)
+        if lc.get("mfma_util"):
+            res["roofline"]["mfma_util"] = dict(lc["mfma_util"], how=lc["mfma_util_how"], measured_in_this_run=True)
+            if "hidden_fwd_2048x2048" in lc["mfma_util"]:
+                res["roofline"]["hidden_fwd_2048x2048"]["mfma_busy_frac"] = lc["mfma_util"]["hidden_fwd_2048x2048"]["mfma_busy_frac"]
+                res["roofline"]["hidden_fwd_2048x2048"]["mfma_busy_frac_source"] = "rocprofv3 --pmc pass of this run"
+        if "error" in lc:
+            res["roofline"]["live_counters_error"] = lc["error"]
         try:
             res["c5_bf16"] = c5_line(dnnse_amd, dev)
         except Exception as e:

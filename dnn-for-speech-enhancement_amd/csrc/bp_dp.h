@@ -16,11 +16,12 @@
 // Memory-model contract (gfx950; LLVM AMDGPU memory model).  No per-workgroup ACQUIRE and no fence in the exchange kernel:
 // a system-scope acquire (buffer_inv sc0 sc1) drops the whole L2 of the executing XCD, and a release + acquire per
 // workgroup made the exchange kernel 5x slower and evicted the L2 under the GEMMs that run beside it (rocprofv3, round 2).
-// The one release on the data path sits in bp_dp_sync: once per layer, one wave on EVERY XCD issues a system-scope release
-// (buffer_wbl2 sc0 sc1 writes back that XCD's whole L2, whoever dirtied it) after the tile count is complete and before
-// the peers are told -- so the in-kernel hand-off no longer leans on the gradient buffer being write-through.  Otherwise
-//   * the gradient buffer is FINE-GRAINED device memory (never cached dirty; peers' mappings of it are uncached)
-//     and is read with system-scope (sc0 sc1) 16-byte loads, so a reader can neither see a stale L2 line nor leave one;
+// Both directions move their data with system-scope WRITE-THROUGH accesses instead, so that nothing is ever left dirty in a
+// writer's L2 and nothing stale can be read through a reader's:
+//   * gradient tiles are written with system-scope (sc0 sc1) write-through stores by the kernel that counts its tiles
+//     (bp_kernels.h epilogue_block<EPI_WGRAD_STORE>; the event path's kernels end with the kernel-boundary release), into
+//     FINE-GRAINED device memory (never cached dirty; peers' mappings of it are uncached), and are read with system-scope
+//     16-byte loads, so a reader can neither see a stale L2 line nor leave one;
 //   * new weights are written with system-scope WRITE-THROUGH (sc0 sc1) 16-byte stores into the (cacheable) parameter
 //     arenas: nothing stays dirty in the writer's L2; the owner's L2 is kept coherent for its local memory by the
 //     fabric's probes, and its L1s are invalidated at the next kernel boundary;
@@ -93,15 +94,12 @@ __global__ void bp_dp_wait_n(const unsigned *flags, DpIdx bases, int world, unsi
 }
 
 // Exchange stream, per layer: (1) wait until the local weight-gradient launch has counted `target` tiles of this layer's
-// segment (EpiArgs::done, bp_wgrad_dma.h; signed distance, the counter only grows), (2) RELEASE: the counted tiles were stored
-// by workgroups on all eight XCDs with plain stores and no fence of their own, so every workgroup of this launch -- one wave
-// each, BP_DP_SYNC_WGS of them, which the dispatcher deals round-robin over the XCDs -- issues one system-scope release, i.e.
-// one L2 write-back on ITS XCD, (3) the last of them to arrive tells every rank and (4) waits for every rank.  One launch: it
-// replaces an event record on the main stream (which cost it a ~7 us bubble), a stream-wait, a signal kernel and a wait kernel.
-// done == null (attach-time probes of the event path): steps 3 and 4 only.
-enum { BP_DP_SYNC_WGS = 16 };
-__global__ void bp_dp_sync(const unsigned *done, unsigned target, unsigned *arrive, DpPeers peers, const unsigned *flags, int world, int sig_index,
-                           int wait_base, unsigned epoch, unsigned long long budget_ticks, unsigned *err, unsigned code)
+// segment (EpiArgs::done, bp_wgrad_dma.h; signed distance, the counter only grows) -- every counted tile was written with
+// write-through stores that its waves drained before counting, so it is in memory --, (2) tell every rank, (3) wait for every
+// rank.  One wave, one launch: it replaces an event record on the main stream (which cost it a ~7 us bubble), a stream-wait, a
+// signal kernel and a wait kernel.
+__global__ void bp_dp_sync(const unsigned *done, unsigned target, DpPeers peers, const unsigned *flags, int world, int sig_index, int wait_base,
+                           unsigned epoch, unsigned long long budget_ticks, unsigned *err, unsigned code)
 {
     const int p = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
@@ -113,13 +111,7 @@ __global__ void bp_dp_sync(const unsigned *done, unsigned target, unsigned *arri
             __builtin_amdgcn_s_sleep(16);
         }
     }
-    __builtin_amdgcn_s_barrier();          // (one wave: orders lane 0's poll in front of everything below)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                     // system scope: this XCD's L2 is written back
-    unsigned last = 0u;
-    if (p == 0) last = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-    last = __builtin_amdgcn_readfirstlane(last);
-    if (!last) return;
-    if (p == 0) __hip_atomic_store(arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_barrier();          // (one wave: orders lane 0's poll in front of the other lanes' stores)
     if (p < world) {
         __hip_atomic_store(peers.flags[p] + sig_index, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (;;) {
@@ -285,11 +277,11 @@ __global__ void bp_dp_probe_fill(float *probe, unsigned round, unsigned rank)
         probe[i] = bp_probe_value(round, rank, i);
 }
 // the same fill with the product's IN-KERNEL hand-off (bp_wgrad_dma.h, EpiArgs::done): plain stores, every wave drains, one
-// lane per workgroup counts (relaxed; bp_dp_sync pays the release) -- no kernel boundary between these stores and the readers
+// lane per workgroup counts -- no kernel boundary between these stores and the readers
 __global__ __launch_bounds__(256) void bp_dp_probe_fill_count(float *probe, unsigned round, unsigned rank, unsigned *done)
 {
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < BP_DP_PROBE_FLOATS; i += gridDim.x * blockDim.x)
-        probe[i] = bp_probe_value(round, rank, i);
+        __hip_atomic_store(probe + i, bp_probe_value(round, rank, i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // write-through, as the tiles
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -71,7 +71,6 @@ struct bp_dp {
     unsigned *flags;              // own flag words (fine-grained device memory, exported)
     unsigned *arrive;             // [BP_MAXLAYER] last-arriver counters of bp_dp_reduce_update
     unsigned *done;               // [BP_MAXLAYER] tiles of layer l's gradient segment stored so far (counted by the wgrad-store kernel itself)
-    unsigned *sync_arrive;        // [BP_MAXLAYER + 1] last-arriver counters of bp_dp_sync's workgroups (+1: the self-test's)
     unsigned done_target[BP_MAXLAYER];   // host: value done[l] reaches when the current minibatch's tiles are in
     bool counters_ok;             // the in-kernel hand-off passed the attach-time self-test (else: event + kernel boundary per group of layers)
     unsigned *err;                // pinned host word the wait kernels raise on timeout
@@ -112,7 +111,7 @@ static void dp_release(bp_handle *h, bool failed)
     if (d->ev_comm) (void)hipEventDestroy(d->ev_comm);
     if (d->comm) (void)hipStreamDestroy(d->comm);
     if (d->grad_fine) { if (h->grad == d->grad_fine) h->grad = d->grad_prev; (void)hipFree(d->grad_fine); }
-    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->done, (void *)d->sync_arrive, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red})
+    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->done, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red})
         if (q) (void)hipFree(q);
     if (d->err) (void)hipHostFree(d->err);
     rdv_close(d->rdv, failed);
@@ -196,7 +195,7 @@ static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad
             if (!c_dead) {
                 const unsigned ep2 = ep + 0x4000u;                     // (flag words only grow; probe word 2 is this direction's)
                 const unsigned long long short_budget = d->budget_ticks < 200000000ull ? d->budget_ticks : 200000000ull;   // <= 2 s
-                hipLaunchKernelGGL(bp_dp_sync, dim3(BP_DP_SYNC_WGS), dim3(64), 0, d->comm, d->done + BP_MAXLAYER, (ep_base + (unsigned)r) * 64u, d->sync_arrive + BP_MAXLAYER, peers, d->flags, d->world,
+                hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + BP_MAXLAYER, (ep_base + (unsigned)r) * 64u, peers, d->flags, d->world,
                                    bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, d->rank), bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, 0), ep2, short_budget, d->err, 3u);
                 hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r + 100u, cnt + 2);
                 hipLaunchKernelGGL(bp_dp_probe_fill_count, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r + 100u, (unsigned)d->rank, d->done + BP_MAXLAYER);
@@ -269,8 +268,6 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     DK(hipMemset(d->arrive, 0, BP_MAXLAYER * sizeof(unsigned)));
     DK(hipMalloc((void **)&d->done, (BP_MAXLAYER + 1) * sizeof(unsigned)));       // (+1: the self-test's counter)
     DK(hipMemset(d->done, 0, (BP_MAXLAYER + 1) * sizeof(unsigned)));
-    DK(hipMalloc((void **)&d->sync_arrive, (BP_MAXLAYER + 1) * sizeof(unsigned)));
-    DK(hipMemset(d->sync_arrive, 0, (BP_MAXLAYER + 1) * sizeof(unsigned)));
     d->counters_ok = transport != BP_DP_TRANSPORT_RCCL;
 #ifdef BP_DEV
     if (dev_flag("BP_DP_NO_COUNTERS")) d->counters_ok = false;    // A/B: the event + kernel-boundary hand-off
@@ -517,11 +514,7 @@ hipError_t dp_bunch(bp_handle *h, int first)
         for (int l = 1; l < L; ++l) {
             done[l] = d->done + l;
             d->done_target[l] += step_wgrad_tiles(h, l);
-            int sync_wgs = BP_DP_SYNC_WGS;
-#ifdef BP_DEV
-            sync_wgs = dev_int("BP_DP_SYNC_WGS", sync_wgs);        // A/B: 1 = release on ONE XCD only (timing comparison, not a valid hand-off across devices)
-#endif
-            hipLaunchKernelGGL(bp_dp_sync, dim3(sync_wgs), dim3(64), 0, d->comm, d->done + l, d->done_target[l], d->sync_arrive + l, peers, d->flags, d->world,
+            hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + l, d->done_target[l], peers, d->flags, d->world,
                                bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->epoch, d->budget_ticks, d->err, 1u);
             CKE(hipGetLastError());
             CKE(dp_reduce_layer(h, l));

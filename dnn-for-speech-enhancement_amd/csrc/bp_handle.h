@@ -104,6 +104,11 @@ struct bp_handle {
     bf16_t *Wb[BP_MAXLAYER];                                 // ONE bf16 shadow of the weights, [prev][cur] (the forward reads it through the LDS transpose read)
     bf16_t *yb[BP_MAXLAYER], *ybT[BP_MAXLAYER];              // [Bp][ld_l], [ld_l][Bp]   (l = 0: the input bunch)
     bf16_t *dxb[BP_MAXLAYER], *dxbT[BP_MAXLAYER];
+#ifdef BP_DEV
+    // experiment (BP_BF16_OVERLAP): the update launches of a bf16 step on a second stream beside the dgrad GEMMs, ordered by
+    // device-side counters instead of events
+    struct { hipStream_t stream; unsigned *cnt; unsigned *err; unsigned steps; bool on; } ov;
+#endif
 };
 
 // Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM loaders (no predicates,

@@ -241,7 +241,10 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cd + ro)) + lob) = d;
                 *reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cw + ro)) + lob) = d + 1.0f * w;   // kernAccSum
             } else {
-                *reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cw + ro)) + lob) = acc[r];
+                // gradient tile of the data-parallel step: SYSTEM-scope write-through stores (sc0 sc1) -- once the wave has drained
+                // vmcnt the tile is in memory whatever kind of allocation the gradient buffer is, which is what lets the tile count
+                // of bp_wgrad_dma.h hand the segment to the peers without a kernel boundary or an L2 write-back (bp_dp.h)
+                __hip_atomic_store(reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cw + ro)) + lob), acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
         return;

@@ -489,6 +489,9 @@ static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int 
                 // instead of 68 MB per launch at the L2's memory side, profiles/r04_bf16_gemm_probe.txt): 2.6 us per launch are not
                 // worth 2.4x the fabric traffic, so both stay within reach of each other's lines.
                 g.k_rot = EPI == BEPI_FWD_HIDDEN ? 4 : 2;
+#ifdef BP_DEV
+                if (EPI == BEPI_FWD_HIDDEN) g.k_rot = dev_int("BP_BF16_ROT_FWD", g.k_rot);   // (tools/run_bf_alias.sh reproduces the sweep)
+#endif
                 hipLaunchKernelGGL((bp_gemm_bf16<EPI, 128, BKN, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
                 return hipGetLastError();
             }
@@ -599,15 +602,8 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
         a.first_tile[cnt] = t; a.n = cnt;
         // fused update: six waves (two of them own W / delta), 64-frame k-tiles in a ring of 3 when the bunch has at least 4;
         // data-parallel gradient store: the four-wave loop alone
-#ifdef BP_DEV
-        static const int persist = dev_int("BP_BF16_UPD_PERSIST", 0);          // A/B: workgroups of the persistent form (0 = off)
-#define BF_DMA_PERSIST(K) if (fused && persist > 0) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six_persist<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(persist < t ? persist : t), dim3(384), 0, h->stream, a); else
-#else
-#define BF_DMA_PERSIST(K)
-#endif
 #define BF_DMA_LAUNCH(K)                                                                                             \
-        do { BF_DMA_PERSIST(K)                                                                                       \
-             if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(t), dim3(384), 0, h->stream, a); \
+        do { if (fused) hipLaunchKernelGGL((bp_wgrad_dma_bf16_six<K, (K >= 256 ? 64 : 32), (K >= 256 ? 3 : 4)>), dim3(t), dim3(384), 0, h->stream, a); \
              else hipLaunchKernelGGL((bp_wgrad_dma_bf16_store<K>), dim3(t), dim3(256), 0, h->stream, a); } while (0)
         switch (h->Bp) {
         case 128: BF_DMA_LAUNCH(128); break;
@@ -616,7 +612,6 @@ static hipError_t bf_wgrads_dma(bp_handle *h, const int *ls, int n, bool fused)
         default: BF_DMA_LAUNCH(1024); break;
         }
 #undef BF_DMA_LAUNCH
-#undef BF_DMA_PERSIST
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return er;
     }
@@ -630,6 +625,83 @@ static hipError_t bf_wgrads(bp_handle *h, const int *ls, int n, bool fused)
     for (int i = 0; i < n; ++i) { const hipError_t er = bf_wgrad(h, ls[i], fused); if (er != hipSuccess) return er; }
     return hipSuccess;
 }
+
+#ifdef BP_DEV
+// ------------------------------------------------------------------ experiment: update launches beside the dgrad GEMMs
+// BP_BF16_OVERLAP=1 (development build only).  The bf16 step is two halves that never overlap: the HBM-bound update launch
+// (MFMA ~11 % busy) and eleven GEMM launches that read their weights from the Infinity Cache and leave HBM idle (VERDICT r4
+// item 1).  Here the update of layer l runs on a SECOND stream as soon as dgrad(l) -- the last reader of Wb_l, and the
+// producer of nothing it needs later than dEdX_l from dgrad(l+1) -- has finished, beside dgrad(l-1) .. dgrad(2); the next
+// step's forward of layer l waits for update(l).  Ordering is by device-side counters and one-wave gate kernels (an event
+// fork/join costs ~20 us on this stack, profiles/r03_overlap_two_streams.txt), spins bounded.
+__global__ void bp_gate_signal(unsigned *c, unsigned v) { if (threadIdx.x == 0) __hip_atomic_store(c, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void bp_gate_wait(const unsigned *c, unsigned v, unsigned long long budget_ticks, unsigned *err)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if ((int)(__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) >= 0) break;
+        if (wall_clock64() - t0 > budget_ticks) { atomicExch(err, 1u); break; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+static int ov_init(bp_handle *h)
+{
+    if (h->ov.stream) return BP_OK;
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(hipStreamCreateWithPriority(&h->ov.stream, hipStreamNonBlocking, dev_flag("BP_BF16_OVERLAP_SAMEPRIO") ? hi : lo));
+    HIPCHK(hipMalloc((void **)&h->ov.cnt, 2 * BP_MAXLAYER * sizeof(unsigned)));
+    HIPCHK(hipMemset(h->ov.cnt, 0, 2 * BP_MAXLAYER * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&h->ov.err, sizeof(unsigned), hipHostMallocMapped));
+    *h->ov.err = 0u;
+    h->ov.steps = 0;
+    return BP_OK;
+}
+static hipError_t ov_wait(bp_handle *h, hipStream_t st, int idx, unsigned v)
+{
+    if (v == 0) return hipSuccess;
+    hipLaunchKernelGGL(bp_gate_wait, dim3(1), dim3(64), 0, st, h->ov.cnt + idx, v, 200000000ull /* 2 s */, h->ov.err);
+    return hipGetLastError();
+}
+static hipError_t ov_signal(bp_handle *h, hipStream_t st, int idx, unsigned v)
+{
+    hipLaunchKernelGGL(bp_gate_signal, dim3(1), dim3(64), 0, st, h->ov.cnt + idx, v);
+    return hipGetLastError();
+}
+// counters: [l] = "dgrad l of step n done" (n = value), [BP_MAXLAYER + l] = "update l of step n done"
+static hipError_t bf_bunch_overlapped(bp_handle *h, const float *x0, const float *tg)
+{
+    const int L = h->L;
+    const unsigned n = h->ov.steps, n1 = n + 1;
+    hipError_t er;
+#define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
+    hipStream_t main_st = h->stream, upd = h->ov.stream;
+    for (int l = 1; l < L; ++l) {
+        CKE(ov_wait(h, main_st, BP_MAXLAYER + l, n));          // update(l) of the previous step (l == 1: also the last reader of the input bunch's bf16 copy)
+        if (l == 1) CKE(bf_input(h, x0, h->B));
+        CKE(bf_fwd(h, l, h->B, tg, nullptr, true, 1.0f));
+    }
+    for (int l = L - 1; l >= 2; --l) { CKE(bf_dgrad(h, l)); CKE(ov_signal(h, main_st, l, n1)); }
+    for (int l = L - 1; l >= 1; --l) {
+        CKE(ov_wait(h, upd, l >= 2 ? l : 2, n1));
+        h->stream = upd;
+        er = bf_wgrads_dma(h, &l, 1, true);
+        h->stream = main_st;
+        if (er != hipSuccess) return er;
+        CKE(ov_signal(h, upd, BP_MAXLAYER + l, n1));
+    }
+    h->ov.steps = n1;
+#undef CKE
+    return hipSuccess;
+}
+// the main stream catches up with the update stream (end of a bp_train_resident call: stream order covers everything again)
+static hipError_t ov_join(bp_handle *h)
+{
+    if (!h->ov.stream || !h->ov.steps) return hipSuccess;
+    return ov_wait(h, h->stream, BP_MAXLAYER + 1, h->ov.steps);
+}
+#endif
 
 // ------------------------------------------------------------------ the pieces of one bunch
 // Where the rows of the bunch starting at chunk frame `first` lie: window chunks are stacked (and masked) into the staging
@@ -690,6 +762,13 @@ hipError_t bunch(bp_handle *h, int first, bool fused)
     int ls[BP_MAXLAYER];
     for (int l = 1; l < L; ++l) ls[l - 1] = l;          // wgrad problems: layer 1 (the largest) first
     if (h->bf) {
+#ifdef BP_DEV
+        if (fused && bf_dma_ok(h) && L >= 3 && dev_flag("BP_BF16_OVERLAP")) {
+            if (ov_init(h) != BP_OK) return hipErrorUnknown;
+            h->ov.on = true;
+            return bf_bunch_overlapped(h, x0, tg);
+        }
+#endif
         for (int l = 1; l < L; ++l) CKE(step_forward(h, l, x0, tg));
         for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));   // every dgrad sees pre-update (shadow) weights
         return bf_wgrads(h, ls, L - 1, fused);
@@ -938,6 +1017,9 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
         return fail(BP_ERR_DEVICE, std::string("bp_train_resident: ") + hipGetErrorString(er));
     }
     if (h->dp && nb > 0) HIPCHK(dp_flush(h));
+#ifdef BP_DEV
+    if (h->ov.on) { HIPCHK(ov_join(h)); if (*(volatile unsigned *)h->ov.err) return fail(BP_ERR_STATE, "overlap experiment: a gate timed out"); }
+#endif
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_bunches = nb;
     return BP_OK;

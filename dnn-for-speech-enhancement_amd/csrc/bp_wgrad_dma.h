@@ -118,7 +118,7 @@ struct WgradDma {
                     const float s = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
                     const int n = n0 + tid;
                     if constexpr (STORE) {
-                        e.bias_g[n] = s;
+                        __hip_atomic_store(e.bias_g + n, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // (write-through, like the tile below)
                     } else {
                         const float d = e.mom * e.bias_d[n] - e.c1 * (s / e.ndiv + 0.0f * e.bias_w[n]);
                         e.bias_d[n] = d;
@@ -131,11 +131,13 @@ struct WgradDma {
             if constexpr (STORE) {
                 // data-parallel step: tell the exchange stream that this tile of the layer's gradient segment is complete, WITHOUT a
                 // kernel boundary (one grouped launch for all layers; the exchange of layer 1 starts while the other layers' tiles
-                // still run).  Every storing wave drains its stores, the workgroup meets at a barrier, then one lane counts the tile
-                // (relaxed).  The RELEASE that makes the counted tiles visible outside this device is not paid here but once per layer
-                // and XCD by bp_dp_sync (bp_dp.h), which the count wakes: a system-scope release per TILE (ADVICE r4's first proposal)
-                // was measured at +91 us per C2 step -- 0.3445 vs 0.2533 ms through the exchange path, profiles/r05_dp_world1.txt --
-                // because every one of the 3648 tiles then waits for an L2 write-back request.
+                // still run).  The tile and the bias gradient were stored with system-scope write-through stores (sc0 sc1,
+                // epilogue_block): every storing wave drains vmcnt -- an acknowledged write-through store is in memory --, the
+                // workgroup meets at a barrier, one lane counts the tile (relaxed, system scope).  That is the store half of the memory
+                // model's own code sequence for system-scope atomics; it needs no L2 write-back because nothing was left dirty.
+                // Measured alternatives (C2 through the exchange path at world 1, profiles/r05_dp_world1.txt): a system-scope RELEASE on
+                // the count (ADVICE r4's first proposal: one buffer_wbl2 per tile, 3648 per step) 0.3445 ms against 0.2533; one release
+                // per layer on every XCD inside bp_dp_sync 0.2750 (16 waves) / 0.2640 (8) against 0.2551.
                 if (e.done) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();

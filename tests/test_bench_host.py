@@ -72,3 +72,47 @@ def test_profiled_traffic_is_stamped_with_the_kernel_sources():
     t, stamp = bench.profiled_traffic("r02_pmc_hbm_traffic.json", lambda k: "bp_wgrad_dma" in k and "grid=" in k and int(k.split("grid=")[1]) > 500000)
     assert t and 2.5e8 < t < 4e8 and stamp["kernel"].startswith("void bp_wgrad_dma") and stamp["matches_current_kernel_sources"] in (None, False)
     assert bench.profiled_traffic("no_such_file.json", lambda k: True) == (None, None)
+
+
+def _launch_check(extra_args=(), extra_env=None):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"] + list(extra_args),
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    return _last_json(r.stdout)
+
+
+def test_multi_gpu_line_times_both_transports_and_takes_the_faster():
+    """north_star names RCCL, the library's default transport is its own peer kernels -- `bench.py --gpus N`
+    alone must answer which is faster.  The selection flow (run_exchanges) is walked here with stand-in timings: both
+    transports attached by the whole group, timed, detached; value = the faster one."""
+    j = _launch_check(extra_env={"BENCH_FAKE_MS": "native:0.31,rccl:0.29"})
+    ex = j["exchange"]
+    assert ex["native"]["ms_per_step"] == 0.31 and ex["rccl"]["ms_per_step"] == 0.29 and ex["chosen"] == "rccl"
+    assert j["detaches"] == [["detach", "native", False], ["detach", "rccl", False]]
+    j = _launch_check(extra_env={"BENCH_FAKE_MS": "native:0.25,rccl:0.29"})
+    assert j["exchange"]["chosen"] == "native"
+
+
+def test_a_transport_that_one_rank_cannot_attach_is_skipped_by_the_whole_group():
+    """A failure seen by ONE rank (here rank 1's native attach) must send every rank the same way: rank 0, which did attach,
+    leaves the broken group, nobody times that transport, the other one supplies the line."""
+    j = _launch_check(extra_env={"BENCH_FAKE_FAIL": "native:1"})
+    ex = j["exchange"]
+    assert "error" in ex["native"] and "1 rank" in ex["native"]["error"] and ex["chosen"] == "rccl" and "ms_per_step" in ex["rccl"]
+    assert j["detaches"][0] == ["detach", "native", True]          # rank 0's log: it had attached and backed out
+
+
+def test_a_single_transport_can_still_be_requested():
+    j = _launch_check(extra_args=["--exchange", "rccl"])
+    assert set(j["exchange"]) == {"rccl", "chosen"} and j["exchange"]["chosen"] == "rccl"
+
+
+def test_cpu_baseline_carries_the_c1_figure(oracle_mod):
+    """CPU baseline for C1 (full) and C2."""
+    import bench
+    from oracle import oracle as O
+    r = bench.cpu_baseline_c1(O, 2, frames=1280, budget_s=1.0)
+    assert r["kind"] == "port" and r["unit"] == "frames/s" and r["value"] > 0 and "257->512->257" in r["sample"]

@@ -1,0 +1,30 @@
+# Round-5 profiles (run on the GPU box through gpurun): rocprofv3 kernel-trace stats of the DRIVER's bench command, separate
+# PMC passes for HBM traffic (FETCH_SIZE / WRITE_SIZE) and SQ counters -- for the fp32 C2 step AND for the bf16 configs[4]
+# per-GPU shape -- each stamped with the sha256 of the kernel sources it was measured on (bench.py compares the stamp with the
+# sources it runs).  New in round 5: profiles/r05_mfma_util.json (tools/pmc_sq_summary.py: MFMA busy over busy-CU cycles).
+set -x
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r05; rm -rf $O; mkdir -p $O
+STAMP=$(cat $R/dnn-for-speech-enhancement_amd/csrc/*.h $R/dnn-for-speech-enhancement_amd/csrc/*.hip | sha256sum | cut -c1-16)
+cd /tmp && export TMPDIR=/tmp
+SHORT="--steps 40 --warmup 10 --no-cpu-baseline --no-extras --prewarm-s 0 --sustained-s 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python $R/bench.py $SHORT > /dev/null 2> $O/f.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python $R/bench.py $SHORT > /dev/null 2> $O/w.err
+python $R/tools/pmc_summary.py $O/fetch $O/write $O/pmc.json "kernel sources sha256[:16] $STAMP; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of python bench.py $SHORT; KB units; FETCH doubled per the gfx950 note in MI355X_MICROARCH.md (wide coalesced reads are tallied at half)"
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "MfmaUtil"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d $O/sq$i -o p -- python $R/bench.py $SHORT > /dev/null 2> $O/sq$i.err
+done
+python $R/tools/pmc_any.py $O/sq.json $O/sq1 $O/sq2 $O/sq3 > $O/sq.txt
+python $R/tools/pmc_sq_summary.py $O/sq.json $O/mfma_util.json $STAMP "rocprofv3 --pmc passes (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES ... | GRBM_GUI_ACTIVE SQ_LDS_* | MfmaUtil) of python bench.py $SHORT" > $O/mfma_util.txt
+# ---- bf16 configs[4] per-GPU shape: kernel stats + HBM traffic + SQ
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o c5 -- python $R/tools/bench_bf16.py c5bf16 > $O/c5.json 2> $O/c5.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c5f -o f -- python $R/tools/bench_bf16.py c5bf16 > /dev/null 2> $O/c5f.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c5w -o w -- python $R/tools/bench_bf16.py c5bf16 > /dev/null 2> $O/c5w.err
+python $R/tools/pmc_summary.py $O/c5f $O/c5w $O/c5_pmc.json "kernel sources sha256[:16] $STAMP; FETCH_SIZE / WRITE_SIZE (separate passes) of python tools/bench_bf16.py c5bf16 (2827->4096x5->257, 512 frames, bf16); KB units; FETCH doubled per the gfx950 note"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/c5sq -o p -- python $R/tools/bench_bf16.py c5bf16 > /dev/null 2> $O/c5sq.err
+python $R/tools/pmc_any.py $O/c5_sq.json $O/c5sq > $O/c5_sq.txt
+python $R/tools/pmc_sq_summary.py $O/c5_sq.json $O/c5_mfma_util.json $STAMP "rocprofv3 --pmc SQ pass of python tools/bench_bf16.py c5bf16" > $O/c5_mfma_util.txt
+echo $STAMP > $O/stamp.txt
+find $O -name "*kernel_stats.csv" | head; find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete; du -sh $O

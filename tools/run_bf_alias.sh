@@ -1,6 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out/bfdma; rm -rf $O; mkdir -p $O
+export BP_HIP_LIB=$R/dnn-for-speech-enhancement_amd/libbp_hip_dev.so      # (make -C dnn-for-speech-enhancement_amd/csrc dev: the build that reads BP_BF16_ROT_FWD)
 timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_autograd.py tests/test_dp_native.py tests/test_bptrain.py tests/test_bpforward.py -m gpu -x -q -k "bf16 or config5 or compute_dtype" > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest.log
 cd /tmp; export TMPDIR=/tmp
 for m in 4 0 2 8 4 0; do
