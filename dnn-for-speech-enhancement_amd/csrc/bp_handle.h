@@ -104,11 +104,6 @@ struct bp_handle {
     bf16_t *Wb[BP_MAXLAYER];                                 // ONE bf16 shadow of the weights, [prev][cur] (the forward reads it through the LDS transpose read)
     bf16_t *yb[BP_MAXLAYER], *ybT[BP_MAXLAYER];              // [Bp][ld_l], [ld_l][Bp]   (l = 0: the input bunch)
     bf16_t *dxb[BP_MAXLAYER], *dxbT[BP_MAXLAYER];
-#ifdef BP_DEV
-    // experiment (BP_BF16_OVERLAP): the update launches of a bf16 step on a second stream beside the dgrad GEMMs, ordered by
-    // device-side counters instead of events
-    struct { hipStream_t stream; unsigned *cnt; unsigned *err; unsigned steps; bool on; } ov;
-#endif
 };
 
 // Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM loaders (no predicates,
@@ -133,7 +128,8 @@ hipError_t step_dgrad(bp_handle *h, int l);                                     
 // weight + bias gradients of layers ls[0..n) into the flat gradient buffer, ONE grouped launch where the kernel set allows it.
 // done != null: done[l] is a device counter every tile of layer l's segment bumps behind its stores (in-kernel hand-off);
 // only legal when step_wgrads_count(h) says the launch really counts.
-hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done);
+// done_mtiles != null: layer l's counters are done[l][tile row / done_mtiles[l]] (the segment is handed over in bands of tile rows).
+hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done, const int *done_mtiles);
 bool step_wgrads_count(const bp_handle *h);
 unsigned step_wgrad_tiles(const bp_handle *h, int l);                                   // tiles of layer l in that launch
 hipError_t step_shadow(bp_handle *h, int l);                                            // fp32 master W_l -> bf16 shadow (bf16 mode)

@@ -626,83 +626,6 @@ static hipError_t bf_wgrads(bp_handle *h, const int *ls, int n, bool fused)
     return hipSuccess;
 }
 
-#ifdef BP_DEV
-// ------------------------------------------------------------------ experiment: update launches beside the dgrad GEMMs
-// BP_BF16_OVERLAP=1 (development build only).  The bf16 step is two halves that never overlap: the HBM-bound update launch
-// (MFMA ~11 % busy) and eleven GEMM launches that read their weights from the Infinity Cache and leave HBM idle (VERDICT r4
-// item 1).  Here the update of layer l runs on a SECOND stream as soon as dgrad(l) -- the last reader of Wb_l, and the
-// producer of nothing it needs later than dEdX_l from dgrad(l+1) -- has finished, beside dgrad(l-1) .. dgrad(2); the next
-// step's forward of layer l waits for update(l).  Ordering is by device-side counters and one-wave gate kernels (an event
-// fork/join costs ~20 us on this stack, profiles/r03_overlap_two_streams.txt), spins bounded.
-__global__ void bp_gate_signal(unsigned *c, unsigned v) { if (threadIdx.x == 0) __hip_atomic_store(c, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ void bp_gate_wait(const unsigned *c, unsigned v, unsigned long long budget_ticks, unsigned *err)
-{
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        if ((int)(__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - v) >= 0) break;
-        if (wall_clock64() - t0 > budget_ticks) { atomicExch(err, 1u); break; }
-        __builtin_amdgcn_s_sleep(16);
-    }
-}
-static int ov_init(bp_handle *h)
-{
-    if (h->ov.stream) return BP_OK;
-    int lo = 0, hi = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPCHK(hipStreamCreateWithPriority(&h->ov.stream, hipStreamNonBlocking, dev_flag("BP_BF16_OVERLAP_SAMEPRIO") ? hi : lo));
-    HIPCHK(hipMalloc((void **)&h->ov.cnt, 2 * BP_MAXLAYER * sizeof(unsigned)));
-    HIPCHK(hipMemset(h->ov.cnt, 0, 2 * BP_MAXLAYER * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void **)&h->ov.err, sizeof(unsigned), hipHostMallocMapped));
-    *h->ov.err = 0u;
-    h->ov.steps = 0;
-    return BP_OK;
-}
-static hipError_t ov_wait(bp_handle *h, hipStream_t st, int idx, unsigned v)
-{
-    if (v == 0) return hipSuccess;
-    hipLaunchKernelGGL(bp_gate_wait, dim3(1), dim3(64), 0, st, h->ov.cnt + idx, v, 200000000ull /* 2 s */, h->ov.err);
-    return hipGetLastError();
-}
-static hipError_t ov_signal(bp_handle *h, hipStream_t st, int idx, unsigned v)
-{
-    hipLaunchKernelGGL(bp_gate_signal, dim3(1), dim3(64), 0, st, h->ov.cnt + idx, v);
-    return hipGetLastError();
-}
-// counters: [l] = "dgrad l of step n done" (n = value), [BP_MAXLAYER + l] = "update l of step n done"
-static hipError_t bf_bunch_overlapped(bp_handle *h, const float *x0, const float *tg)
-{
-    const int L = h->L;
-    const unsigned n = h->ov.steps, n1 = n + 1;
-    hipError_t er;
-#define CKE(x) do { er = (x); if (er != hipSuccess) return er; } while (0)
-    hipStream_t main_st = h->stream, upd = h->ov.stream;
-    for (int l = 1; l < L; ++l) {
-        CKE(ov_wait(h, main_st, BP_MAXLAYER + l, n));          // update(l) of the previous step (l == 1: also the last reader of the input bunch's bf16 copy)
-        if (l == 1) CKE(bf_input(h, x0, h->B));
-        CKE(bf_fwd(h, l, h->B, tg, nullptr, true, 1.0f));
-    }
-    for (int l = L - 1; l >= 2; --l) { CKE(bf_dgrad(h, l)); CKE(ov_signal(h, main_st, l, n1)); }
-    for (int l = L - 1; l >= 1; --l) {
-        CKE(ov_wait(h, upd, l >= 2 ? l : 2, n1));
-        h->stream = upd;
-        er = bf_wgrads_dma(h, &l, 1, true);
-        h->stream = main_st;
-        if (er != hipSuccess) return er;
-        CKE(ov_signal(h, upd, BP_MAXLAYER + l, n1));
-    }
-    h->ov.steps = n1;
-#undef CKE
-    return hipSuccess;
-}
-// the main stream catches up with the update stream (end of a bp_train_resident call: stream order covers everything again)
-static hipError_t ov_join(bp_handle *h)
-{
-    if (!h->ov.stream || !h->ov.steps) return hipSuccess;
-    return ov_wait(h, h->stream, BP_MAXLAYER + 1, h->ov.steps);
-}
-#endif
-
 // ------------------------------------------------------------------ the pieces of one bunch
 // Where the rows of the bunch starting at chunk frame `first` lie: window chunks are stacked (and masked) into the staging
 // tile now, stacked chunks are read in place or from their masked copy.
@@ -737,13 +660,13 @@ hipError_t step_dgrad(bp_handle *h, int l) { return h->bf ? bf_dgrad(h, l) : lau
 // (fp32: the LDS-DMA store kernel of the static bunch sizes is the one that counts its tiles, up to 4 layers per launch)
 bool step_wgrads_count(const bp_handle *h) { return !h->bf && (h->B == 128 || h->B == 256 || h->B == 512) && h->L - 1 <= 4; }
 unsigned step_wgrad_tiles(const bp_handle *h, int l) { return (unsigned)(((h->ld[l - 1] + 63) / 64) * ((h->ld[l] + 63) / 64)); }
-hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done)
+hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done, const int *done_mtiles)
 {
     if (h->bf) return bf_wgrads(h, ls, n, false);
     Prepared ws[BP_MAXLAYER];
     for (int i = 0; i < n; ++i) {
         ws[i] = prep_wgrad(h, ls[i], h->B, ls[i] == 1 ? x0 : h->y[ls[i] - 1], false);
-        if (done) ws[i].e.done = done[ls[i]];
+        if (done) { ws[i].e.done = done[ls[i]]; ws[i].e.done_mtiles = done_mtiles ? done_mtiles[ls[i]] : 0; }
     }
     return run_wgrads(h->stream, ws, n);
 }
@@ -762,13 +685,6 @@ hipError_t bunch(bp_handle *h, int first, bool fused)
     int ls[BP_MAXLAYER];
     for (int l = 1; l < L; ++l) ls[l - 1] = l;          // wgrad problems: layer 1 (the largest) first
     if (h->bf) {
-#ifdef BP_DEV
-        if (fused && bf_dma_ok(h) && L >= 3 && dev_flag("BP_BF16_OVERLAP")) {
-            if (ov_init(h) != BP_OK) return hipErrorUnknown;
-            h->ov.on = true;
-            return bf_bunch_overlapped(h, x0, tg);
-        }
-#endif
         for (int l = 1; l < L; ++l) CKE(step_forward(h, l, x0, tg));
         for (int l = L - 1; l >= 2; --l) CKE(bf_dgrad(h, l));   // every dgrad sees pre-update (shadow) weights
         return bf_wgrads(h, ls, L - 1, fused);
@@ -1017,9 +933,6 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
         return fail(BP_ERR_DEVICE, std::string("bp_train_resident: ") + hipGetErrorString(er));
     }
     if (h->dp && nb > 0) HIPCHK(dp_flush(h));
-#ifdef BP_DEV
-    if (h->ov.on) { HIPCHK(ov_join(h)); if (*(volatile unsigned *)h->ov.err) return fail(BP_ERR_STATE, "overlap experiment: a gate timed out"); }
-#endif
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     h->last_bunches = nb;
     return BP_OK;
