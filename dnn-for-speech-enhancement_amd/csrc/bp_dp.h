@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
     __syncthreads();
     if (last) {
         if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (a.flag_index >= 0 && (int)threadIdx.x < world)          // (< 0: not the layer's last piece -- "weights gathered" is not due yet)
+        if ((int)threadIdx.x < world)
             __hip_atomic_store(a.peers.flags[threadIdx.x] + a.flag_index, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

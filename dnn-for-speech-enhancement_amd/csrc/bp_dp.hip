@@ -14,7 +14,6 @@
 #include "bp_dp.h"
 #include "bp_rdv.h"
 
-enum { BP_DP_MAXSLABS = 4 };
 struct ncclUniqueIdBytes { char internal[128]; };   // = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128), passed by value
 
 // ------------------------------------------------------------------ host rendezvous (bp_rdv.h), C ABI
@@ -71,13 +70,8 @@ struct bp_dp {
     float *probe_p, *probe_g;     // self-test probes: ordinary (like the parameter arena) / fine-grained (like the gradient buffer)
     unsigned *flags;              // own flag words (fine-grained device memory, exported)
     unsigned *arrive;             // [BP_MAXLAYER] last-arriver counters of bp_dp_reduce_update
-    // Tile-counter path: a layer's segment is handed over in up to BP_DP_MAXSLABS PIECES (bands of 64-row tile rows of W, i.e.
-    // contiguous flat ranges; the last one carries the bias part).  Layer 1 -- the largest segment, first in the grouped launch
-    // and first needed by the next forward -- goes in four: its exchange starts a quarter into its tiles instead of behind them,
-    // which moves the whole chain on the exchange stream earlier.  Every other layer / path: one piece.
-    int nslab[BP_MAXLAYER], slab_mtiles[BP_MAXLAYER];
-    unsigned *done;               // [BP_MAXLAYER * BP_DP_MAXSLABS + 1] tiles of piece (l, s) stored so far (counted by the wgrad-store kernel itself; +1: self-test)
-    unsigned done_target[BP_MAXLAYER * BP_DP_MAXSLABS];   // host: value done[l, s] reaches when the current minibatch's tiles are in
+    unsigned *done;               // [BP_MAXLAYER] tiles of layer l's gradient segment stored so far (counted by the wgrad-store kernel itself)
+    unsigned done_target[BP_MAXLAYER];   // host: value done[l] reaches when the current minibatch's tiles are in
     bool counters_ok;             // the in-kernel hand-off passed the attach-time self-test (else: event + kernel boundary per group of layers)
     unsigned *err;                // pinned host word the wait kernels raise on timeout
     hipStream_t comm;             // exchange stream: signal -> wait -> reduce/update/all-gather per layer
@@ -85,6 +79,7 @@ struct bp_dp {
     hipEvent_t ev_w[BP_MAXLAYER]; // comm stream (RCCL backend): the weights of layer l have been gathered
     hipEvent_t ev_comm;           // comm stream: everything queued so far is done (flush)
     unsigned epoch;               // minibatches exchanged so far (flag value of the current one)
+    size_t lo[BP_MAXLAYER], hi[BP_MAXLAYER];   // this rank's slice of layer l's flat segment
     unsigned long long budget_ticks;
     bool peers_open;
     RcclApi rccl; void *rccl_comm; float *red;   // RCCL backend: communicator, reduce-scatter landing buffer (largest slice)
@@ -200,10 +195,10 @@ static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad
             if (!c_dead) {
                 const unsigned ep2 = ep + 0x4000u;                     // (flag words only grow; probe word 2 is this direction's)
                 const unsigned long long short_budget = d->budget_ticks < 200000000ull ? d->budget_ticks : 200000000ull;   // <= 2 s
-                hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + BP_MAXLAYER * BP_DP_MAXSLABS, (ep_base + (unsigned)r) * 64u, peers, d->flags, d->world,
+                hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + BP_MAXLAYER, (ep_base + (unsigned)r) * 64u, peers, d->flags, d->world,
                                    bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, d->rank), bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, 0), ep2, short_budget, d->err, 3u);
                 hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r + 100u, cnt + 2);
-                hipLaunchKernelGGL(bp_dp_probe_fill_count, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r + 100u, (unsigned)d->rank, d->done + BP_MAXLAYER * BP_DP_MAXSLABS);
+                hipLaunchKernelGGL(bp_dp_probe_fill_count, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r + 100u, (unsigned)d->rank, d->done + BP_MAXLAYER);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipStreamSynchronize(h->stream));
                 HIPCHK(hipStreamSynchronize(d->comm));
@@ -271,8 +266,8 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     DK(hipMemset(d->flags, 0, BP_DP_FLAG_WORDS * sizeof(unsigned)));
     DK(hipMalloc((void **)&d->arrive, BP_MAXLAYER * sizeof(unsigned)));
     DK(hipMemset(d->arrive, 0, BP_MAXLAYER * sizeof(unsigned)));
-    DK(hipMalloc((void **)&d->done, (BP_MAXLAYER * BP_DP_MAXSLABS + 1) * sizeof(unsigned)));       // (+1: the self-test's counter)
-    DK(hipMemset(d->done, 0, (BP_MAXLAYER * BP_DP_MAXSLABS + 1) * sizeof(unsigned)));
+    DK(hipMalloc((void **)&d->done, (BP_MAXLAYER + 1) * sizeof(unsigned)));       // (+1: the self-test's counter)
+    DK(hipMemset(d->done, 0, (BP_MAXLAYER + 1) * sizeof(unsigned)));
     d->counters_ok = transport != BP_DP_TRANSPORT_RCCL;
 #ifdef BP_DEV
     if (dev_flag("BP_DP_NO_COUNTERS")) d->counters_ok = false;    // A/B: the event + kernel-boundary hand-off
@@ -299,9 +294,10 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     DK(hipEventCreateWithFlags(&d->ev_comm, hipEventDisableTiming));
     DK(hipStreamSynchronize(h->stream));
     size_t max_slice = 4;
-    for (int l = 1; l < h->L; ++l) {                           // one piece per layer until the hand-off form is known (end of attach)
-        d->nslab[l] = 1; d->slab_mtiles[l] = h->ld[l - 1] / 64;
+    for (int l = 1; l < h->L; ++l) {                           // equal float4-aligned slices of [W_l|b_l]
         const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + world - 1) / world;
+        const size_t a = per4 * rank < cnt4 ? per4 * rank : cnt4, b = per4 * (rank + 1) < cnt4 ? per4 * (rank + 1) : cnt4;
+        d->lo[l] = h->g_off[l] + 4 * a; d->hi[l] = h->g_off[l] + 4 * b;
         if (4 * per4 > max_slice) max_slice = 4 * per4;
         if (transport == BP_DP_TRANSPORT_RCCL && per4 * world != cnt4) { dp_release(h, true); return fail(BP_ERR_ARG, "bp_dp_attach: RCCL transport: layer segment not divisible by the world"); }
     }
@@ -371,17 +367,6 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
             if (mode == 1) { dp_release(h, true); return fail(BP_ERR_STATE, "bp_dp_attach: self-test failed: stale weights after a peer's write-through stores even with an explicit acquire (" + std::to_string(tw) + " words)"); }
         }
     }
-    // the hand-off form is known now: on the tile-counter path layer 1's segment goes out in (up to) four pieces
-    if (d->counters_ok && transport != BP_DP_TRANSPORT_RCCL && step_wgrads_count(h)) {
-        int want = BP_DP_MAXSLABS;
-#ifdef BP_DEV
-        want = dev_int("BP_DP_SLABS", want);
-        if (want < 1) want = 1;
-        if (want > BP_DP_MAXSLABS) want = BP_DP_MAXSLABS;
-#endif
-        const int mt = h->ld[0] / 64, per = (mt + want - 1) / want;
-        d->slab_mtiles[1] = per; d->nslab[1] = (mt + per - 1) / per;
-    }
 #undef DK
 #undef DR
     return BP_OK;
@@ -410,46 +395,16 @@ static hipError_t dp_wait_weights(bp_handle *h, int l, unsigned epoch)
     return hipGetLastError();
 }
 
-// flat range of piece s of layer l (all ranks' parts together); the last piece carries the bias part behind W
-static void dp_piece(const bp_handle *h, int l, int s, size_t *lo, size_t *hi)
-{
-    const bp_dp *d = h->dp;
-    const size_t ld = (size_t)h->ld[l], band = (size_t)64 * d->slab_mtiles[l] * ld;
-    *lo = h->g_off[l] + band * s;
-    *hi = s + 1 == d->nslab[l] ? h->g_off[l] + h->g_cnt[l] : h->g_off[l] + band * (s + 1);
-}
-// rank p's part of it: equal float4-aligned parts (the momentum state of that part lives on rank p only)
-static void dp_part(const bp_handle *h, int l, int s, int p, size_t *lo, size_t *hi)
-{
-    size_t a, b;
-    dp_piece(h, l, s, &a, &b);
-    const size_t cnt4 = (b - a) / 4, per4 = (cnt4 + h->dp->world - 1) / h->dp->world;
-    const size_t x = per4 * p < cnt4 ? per4 * p : cnt4, y = per4 * (p + 1) < cnt4 ? per4 * (p + 1) : cnt4;
-    *lo = a + 4 * x; *hi = a + 4 * y;
-}
-static unsigned dp_piece_tiles(const bp_handle *h, int l, int s)
-{
-    const bp_dp *d = h->dp;
-    const int mt = h->ld[l - 1] / 64, first = d->slab_mtiles[l] * s;
-    const int rows = s + 1 == d->nslab[l] ? mt - first : d->slab_mtiles[l];
-    return (unsigned)(rows * (h->ld[l] / 64));
-}
-// flag slot of "gradient piece ready": slot l for the first piece of layer l, 8 + s for the further pieces (layer 1 only)
-static int dp_grad_slot(int l, int s) { return s == 0 ? l : 8 + s; }
-
-static void dp_update_args(bp_handle *h, int l, int s, DpReduceArgs &a)
+static void dp_update_args(bp_handle *h, int l, DpReduceArgs &a)
 {
     bp_dp *d = h->dp;
     memset(&a, 0, sizeof(a));
-    size_t lo, hi;
-    dp_part(h, l, s, d->rank, &lo, &hi);
-    a.delta = h->deltas; a.lo = lo; a.hi = hi;
+    a.delta = h->deltas; a.lo = d->lo[l]; a.hi = d->hi[l];
     a.w_end = h->g_off[l] + (size_t)h->ld[l - 1] * h->ld[l];
     a.world = d->world; a.rank = d->rank;
     const float m = h->cfg.momentum, lr = h->cfg.lrate;
     a.mom = m; a.c1 = h->cfg.momentum_rule == 1 ? lr : (1 - m) * lr; a.wc = h->cfg.weightcost; a.ndiv = (float)h->Bg;
-    a.arrive = d->arrive + l; a.peers = dp_peers(d); a.epoch = d->epoch;
-    a.flag_index = s + 1 == d->nslab[l] ? bp_dp_flag_index(BP_DP_FLAG_W, l, d->rank) : -1;     // "weights l gathered" rises behind the LAST piece
+    a.arrive = d->arrive + l; a.peers = dp_peers(d); a.flag_index = bp_dp_flag_index(BP_DP_FLAG_W, l, d->rank); a.epoch = d->epoch;
 }
 static int dp_update_grid(const DpReduceArgs &a, int layer)
 {
@@ -466,12 +421,12 @@ static int dp_update_grid(const DpReduceArgs &a, int layer)
     return grid < 1 ? 1 : grid;                                // (an empty slice still raises its flag)
 }
 
-// comm stream: reduce this rank's part of piece (l, s) over all ranks, update it, write the new weights to every rank (native transport)
-static hipError_t dp_reduce_piece(bp_handle *h, int l, int s)
+// comm stream: reduce this rank's slice of layer l over all ranks, update it, write the new weights to every rank (native transport)
+static hipError_t dp_reduce_layer(bp_handle *h, int l)
 {
     bp_dp *d = h->dp;
     DpReduceArgs a;
-    dp_update_args(h, l, s, a);
+    dp_update_args(h, l, a);
     for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
     const int grid = dp_update_grid(a, l);
     switch (d->world) {
@@ -503,11 +458,11 @@ static hipError_t dp_exchange_layers(bp_handle *h, const int *ls, int n)
     for (int i = 0; i < n; ++i) {
         const int l = ls[i];
         DpReduceArgs a;
-        dp_update_args(h, l, 0, a);                                // (event path and RCCL: one piece per layer)
+        dp_update_args(h, l, a);
         if (d->backend == BP_DP_TRANSPORT_RCCL) {
             // reduce-scatter of the segment into `red` (this rank's slice), sharded update on it, all-gather of the new W
             // slice in place in the parameter arena; RCCL orders the ranks, the event orders the next forward of this layer
-            const size_t cnt = a.hi - a.lo;
+            const size_t cnt = d->hi[l] - d->lo[l];
             int e = d->rccl.ReduceScatter(h->grad + h->g_off[l], d->red, cnt, 7 /* ncclFloat32 */, 0 /* ncclSum */, d->rccl_comm, d->comm);
             if (e != 0) return hipErrorUnknown;
             a.grads[0] = d->red - a.lo;                            // the kernel indexes grads[p] + lo
@@ -516,12 +471,12 @@ static hipError_t dp_exchange_layers(bp_handle *h, const int *ls, int n)
             a.peers.flags[0] = d->flags;                           // (flag raised on this rank only; nobody waits for it)
             hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(dp_update_grid(a, l)), dim3(256), 0, d->comm, a);
             if ((er = hipGetLastError()) != hipSuccess) return er;
-            e = d->rccl.AllGather(h->params + a.lo, h->params + h->g_off[l], cnt, 7, d->rccl_comm, d->comm);
+            e = d->rccl.AllGather(h->params + d->lo[l], h->params + h->g_off[l], cnt, 7, d->rccl_comm, d->comm);
             if (e != 0) return hipErrorUnknown;
             if ((er = hipEventRecord(d->ev_w[l], d->comm)) != hipSuccess) return er;
             continue;
         }
-        if ((er = dp_reduce_piece(h, l, 0)) != hipSuccess) return er;
+        if ((er = dp_reduce_layer(h, l)) != hipSuccess) return er;
     }
     return hipSuccess;
 }
@@ -557,25 +512,21 @@ hipError_t dp_bunch(bp_handle *h, int first)
         unsigned *done[BP_MAXLAYER] = {nullptr};
         const DpPeers peers = dp_peers(d);
         for (int l = 1; l < L; ++l) {
-            done[l] = d->done + l * BP_DP_MAXSLABS;
-            for (int s = 0; s < d->nslab[l]; ++s) {
-                const int k = l * BP_DP_MAXSLABS + s;
-                d->done_target[k] += dp_piece_tiles(h, l, s);
-                hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + k, d->done_target[k], peers, d->flags, d->world,
-                                   bp_dp_flag_index(BP_DP_FLAG_GRAD, dp_grad_slot(l, s), d->rank), bp_dp_flag_index(BP_DP_FLAG_GRAD, dp_grad_slot(l, s), 0), d->epoch,
-                                   d->budget_ticks, d->err, 1u);
-                CKE(hipGetLastError());
-                CKE(dp_reduce_piece(h, l, s));
-            }
+            done[l] = d->done + l;
+            d->done_target[l] += step_wgrad_tiles(h, l);
+            hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + l, d->done_target[l], peers, d->flags, d->world,
+                               bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->epoch, d->budget_ticks, d->err, 1u);
+            CKE(hipGetLastError());
+            CKE(dp_reduce_layer(h, l));
         }
-        CKE(step_wgrads_store(h, all, nall, x0, done, d->slab_mtiles));
+        CKE(step_wgrads_store(h, all, nall, x0, done));
     } else {
         // layer 1 (the largest segment, needed first by the next forward) goes out alone; the rest as ONE grouped launch:
         // its exchange queues behind layer 1's on the comm stream anyway, and one launch + one event replace L-2 of each
-        CKE(step_wgrads_store(h, all, 1, x0, nullptr, nullptr));
+        CKE(step_wgrads_store(h, all, 1, x0, nullptr));
         CKE(dp_exchange_layers(h, all, 1));
         if (nall > 1) {
-            CKE(step_wgrads_store(h, all + 1, nall - 1, x0, nullptr, nullptr));
+            CKE(step_wgrads_store(h, all + 1, nall - 1, x0, nullptr));
             CKE(dp_exchange_layers(h, all + 1, nall - 1));
         }
     }
@@ -604,18 +555,18 @@ int dp_gather_deltas(bp_handle *h)
     bp_dp *d = h->dp;
     HIPCHK(hipStreamSynchronize(h->stream));
     if (rdv_barrier(d->rdv) != 0) return fail(BP_ERR_STATE, g_rdv_err);   // every rank quiescent: slices are final
-    for (int l = 1; l < h->L; ++l)
-        for (int s = 0; s < d->nslab[l]; ++s)
-            for (int p = 0; p < d->world; ++p) {
-                if (p == d->rank) continue;
-                size_t lo, hi;
-                dp_part(h, l, s, p, &lo, &hi);
-                if (hi <= lo) continue;
-                const size_t n4 = (hi - lo) / 4;
-                int grid = (int)((n4 + 255) / 256); if (grid > 1024) grid = 1024;
-                hipLaunchKernelGGL(bp_dp_copy, dim3(grid), dim3(256), 0, h->stream, h->deltas + lo, d->p_deltas[p] + lo, (unsigned long long)n4);
-                HIPCHK(hipGetLastError());
-            }
+    for (int l = 1; l < h->L; ++l) {
+        const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + d->world - 1) / d->world;
+        for (int p = 0; p < d->world; ++p) {
+            if (p == d->rank) continue;
+            const size_t a = per4 * p < cnt4 ? per4 * p : cnt4, b = per4 * (p + 1) < cnt4 ? per4 * (p + 1) : cnt4;
+            if (b <= a) continue;
+            const size_t off = h->g_off[l] + 4 * a;
+            int grid = (int)((b - a + 255) / 256); if (grid > 1024) grid = 1024;
+            hipLaunchKernelGGL(bp_dp_copy, dim3(grid), dim3(256), 0, h->stream, h->deltas + off, d->p_deltas[p] + off, (unsigned long long)(b - a));
+            HIPCHK(hipGetLastError());
+        }
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (rdv_barrier(d->rdv) != 0) return fail(BP_ERR_STATE, g_rdv_err);   // nobody resumes training while a peer still reads
     return BP_OK;

@@ -128,8 +128,7 @@ hipError_t step_dgrad(bp_handle *h, int l);                                     
 // weight + bias gradients of layers ls[0..n) into the flat gradient buffer, ONE grouped launch where the kernel set allows it.
 // done != null: done[l] is a device counter every tile of layer l's segment bumps behind its stores (in-kernel hand-off);
 // only legal when step_wgrads_count(h) says the launch really counts.
-// done_mtiles != null: layer l's counters are done[l][tile row / done_mtiles[l]] (the segment is handed over in bands of tile rows).
-hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done, const int *done_mtiles);
+hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done);
 bool step_wgrads_count(const bp_handle *h);
 unsigned step_wgrad_tiles(const bp_handle *h, int l);                                   // tiles of layer l in that launch
 hipError_t step_shadow(bp_handle *h, int l);                                            // fp32 master W_l -> bf16 shadow (bf16 mode)

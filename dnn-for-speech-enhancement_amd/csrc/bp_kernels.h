@@ -73,7 +73,6 @@ struct EpiArgs {
     const uint8_t *mask; int ldmask; // injected dropout mask of the produced activation ([row][unit] bytes, 1 = drop;
                                      // bp_train_resident_masked, parity tests only) -- replaces the Philox draw
     unsigned *done;                  // wgrad store (data parallel): +1 per finished tile, for the exchange stream (bp_dp.h); may be null
-    int done_mtiles;                 // > 0: the tile of tile row m counts into done[m / done_mtiles] (segment handed over in bands of tile rows)
 };
 
 // ------------------------------------------------------------------ Philox4x32-10

@@ -660,13 +660,13 @@ hipError_t step_dgrad(bp_handle *h, int l) { return h->bf ? bf_dgrad(h, l) : lau
 // (fp32: the LDS-DMA store kernel of the static bunch sizes is the one that counts its tiles, up to 4 layers per launch)
 bool step_wgrads_count(const bp_handle *h) { return !h->bf && (h->B == 128 || h->B == 256 || h->B == 512) && h->L - 1 <= 4; }
 unsigned step_wgrad_tiles(const bp_handle *h, int l) { return (unsigned)(((h->ld[l - 1] + 63) / 64) * ((h->ld[l] + 63) / 64)); }
-hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done, const int *done_mtiles)
+hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0, unsigned *const *done)
 {
     if (h->bf) return bf_wgrads(h, ls, n, false);
     Prepared ws[BP_MAXLAYER];
     for (int i = 0; i < n; ++i) {
         ws[i] = prep_wgrad(h, ls[i], h->B, ls[i] == 1 ? x0 : h->y[ls[i] - 1], false);
-        if (done) { ws[i].e.done = done[ls[i]]; ws[i].e.done_mtiles = done_mtiles ? done_mtiles[ls[i]] : 0; }
+        if (done) ws[i].e.done = done[ls[i]];
     }
     return run_wgrads(h->stream, ws, n);
 }

@@ -141,7 +141,7 @@ struct WgradDma {
                 if (e.done) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __syncthreads();
-                    if (tid == 0) __hip_atomic_fetch_add(e.done + (e.done_mtiles > 0 ? tile_m / e.done_mtiles : 0), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (tid == 0) __hip_atomic_fetch_add(e.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         }
