@@ -402,25 +402,35 @@ def launch_ranks(args):
         sys.exit(1)
 
 
-def run_exchanges(plan, attach, detach, timed, group_failed):
+def choose(out):
+    ok = {k: v for k, v in out.items() if isinstance(v, dict) and "ms_per_step" in v}
+    return min(ok, key=lambda k: ok[k]["ms_per_step"]) if ok else None
+
+
+def run_exchanges(plan, attach, detach, timed, group_failed, guard=None):
     """The N > 1 flow: every transport in `plan` is attached AS A GROUP (a failure seen by one rank alone -- a timeout, a
     self-test verdict -- is all-gathered first, so the ranks always agree on what runs next: ADVICE r3), timed, detached.
     Returns ({transport: timing dict | {"error": ...}}, chosen transport or None).  The callbacks are the GPU-side pieces;
-    --launch-check passes stand-ins, which is how this control flow is covered on the CPU (tests/test_bench_host.py)."""
+    --launch-check passes stand-ins, which is how this control flow is covered on the CPU (tests/test_bench_host.py).
+    guard(tr, out_so_far) -> cancel(): armed around every transport AFTER one has already been timed -- a collective library
+    that hangs in its bootstrap must not cost the run the number it already has (the watchdog prints the line and ends the rank)."""
     out = {}
     for tr in plan:
-        err = attach(tr)                                  # None, or this rank's error text
-        n_failed = group_failed(tr, err)
-        if n_failed:
-            if err is None:
-                detach(tr, broken=True)                   # attached here, but a peer was not: leave that group
-            out[tr] = {"error": "attach failed on %d rank(s): %s" % (int(n_failed), err or "on a peer")}
-            continue
-        out[tr] = timed(tr)
-        detach(tr, broken=False)
-    ok = {k: v for k, v in out.items() if "ms_per_step" in v}
-    chosen = min(ok, key=lambda k: ok[k]["ms_per_step"]) if ok else None
-    return out, chosen
+        cancel = guard(tr, dict(out)) if (guard and choose(out)) else None
+        try:
+            err = attach(tr)                              # None, or this rank's error text
+            n_failed = group_failed(tr, err)
+            if n_failed:
+                if err is None:
+                    detach(tr, broken=True)               # attached here, but a peer was not: leave that group
+                out[tr] = {"error": "attach failed on %d rank(s): %s" % (int(n_failed), err or "on a peer")}
+                continue
+            out[tr] = timed(tr)
+            detach(tr, broken=False)
+        finally:
+            if cancel:
+                cancel()
+    return out, choose(out)
 
 
 def live_pmc(counters, timeout_s=150.0):
@@ -499,6 +509,32 @@ def committed_mfma_util():
         return None
 
 
+def make_guard(rank, make_line):
+    """Watchdog around a further transport once one has been timed (run_exchanges): after BENCH_WATCHDOG_S seconds (default 240)
+    rank 0 prints the line from what was measured before, every rank ends.  A thread, not a signal: the hang this is for sits
+    inside a foreign call (a collective library's bootstrap), where Python never gets to run a signal handler."""
+    import threading
+    limit = float(os.environ.get("BENCH_WATCHDOG_S", "240"))
+
+    def guard(tr, out_so_far):
+        def fire():
+            out = dict(out_so_far)
+            out[tr] = {"error": "no result within %.0f s (watchdog); the line reports what was measured before it" % limit}
+            if rank == 0:
+                try:
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
+                except Exception:
+                    pass
+                print(json.dumps(make_line(out, choose(out))), flush=True)
+            os._exit(0)
+        t = threading.Timer(limit, fire)
+        t.daemon = True
+        t.start()
+        return t.cancel
+    return guard
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -537,16 +573,23 @@ def main():
         # fail, BENCH_FAKE_MS="native:0.31,rccl:0.29" are the stand-in step times
         fail_spec = dict(x.split(":") for x in os.environ.get("BENCH_FAKE_FAIL", "").split(",") if ":" in x)
         ms_spec = {k: float(v) for k, v in (x.split(":") for x in os.environ.get("BENCH_FAKE_MS", "native:0.30,rccl:0.35").split(",") if ":" in x)}
+        hang_spec = dict(x.split(":") for x in os.environ.get("BENCH_FAKE_HANG", "").split(",") if ":" in x)   # "rccl:1": rank 1 never returns from attaching rccl
         log = []
-        ex, chosen = run_exchanges(plan,
-                                   attach=lambda tr: ("stand-in failure" if fail_spec.get(tr) == str(rank) else None),
+
+        def lc_line(ex, chosen):
+            return {"launch_check": True, "n_gpus": world, "ranks": list(range(world)), "pids": [int(p) for p in pids],
+                    "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1", "exchange": dict(ex, chosen=chosen), "detaches": log}
+
+        def lc_attach(tr):
+            if hang_spec.get(tr) == str(rank):
+                time.sleep(1e6)
+            return "stand-in failure" if fail_spec.get(tr) == str(rank) else None
+        ex, chosen = run_exchanges(plan, attach=lc_attach,
                                    detach=lambda tr, broken: log.append(("detach", tr, broken)),
                                    timed=lambda tr: {"ms_per_step": ms_spec.get(tr, 1.0), "steps": args.steps},
-                                   group_failed=group_failed)
+                                   group_failed=group_failed, guard=make_guard(rank, lc_line))
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": list(range(world)), "pids": [int(p) for p in pids],
-                              "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
-                              "exchange": dict(ex, chosen=chosen), "detaches": log}), flush=True)
+            print(json.dumps(lc_line(ex, chosen)), flush=True)
         rv.close()
         return
 
@@ -642,41 +685,45 @@ def main():
             if not broken:                                    # (a broken group's closing barrier cannot complete: expected)
                 raise
 
+    def make_line(exchange, chosen, head=None):
+        """the JSON line's common part; dp: from the transports timed so far (also what the watchdog prints)"""
+        if head is None:
+            head = exchange[chosen]
+        res = {
+            "metric": "training frames/sec (257x11 input, 3x2048 DNN)", "value": head["value"], "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "prewarm_s": head["prewarm_s"], "prewarm_steps": head["prewarm_steps"], "sustained": head.get("sustained"),
+            "config": {"workload": "C2: 2827->2048->2048->2048->257 ReLU+dropout(0.1/0.2), fp32, %d frames/GPU/step "
+                                   "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
+                                   % (BUNCH, BUNCH * world, chunk),
+                       "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world,
+                       "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if chosen == "rccl" else
+                                     "in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)") if dp else "none"),
+                       "launcher": "self (bench.py forked its ranks)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else
+                                   ("torch.distributed.run" if world > 1 else "single process")},
+        }
+        if dp:
+            # north_star names RCCL; the library's default is its own peer kernels: ONE run answers which is faster here
+            res["exchange"] = {k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "value", "steps", "error", "dp_acquire_mode", "sustained")})
+                               for k, v in exchange.items()}
+            res["exchange"]["chosen"] = chosen
+            res["exchange"]["note"] = "every transport listed was attached by the whole group and timed with the same protocol in this run; value = the faster one"
+            res["ranks"] = head["ranks"]
+            res["distinct_devices"] = head["distinct_devices"]
+            res["dp_acquire_mode"] = head["dp_acquire_mode"]
+        res["step_frac_of_mfma_peak"] = flops_per_frame(LAYERS) * head["value"] / world / 1e12 / PEAK_MFMA_F32_TF
+        return res
+
     exchange, chosen = None, None
     if dp:
-        exchange, chosen = run_exchanges(plan, attach, detach, timed, group_failed)
+        exchange, chosen = run_exchanges(plan, attach, detach, timed, group_failed, guard=make_guard(rank, make_line))
         if chosen is None:
             raise dnnse_amd.BPError("no data-parallel transport could be attached: %s" % json.dumps(exchange))
-        head = exchange[chosen]
+        res = make_line(exchange, chosen)
     else:
-        head = timed(None)
-
-    value = head["value"]
-    res = {
-        "metric": "training frames/sec (257x11 input, 3x2048 DNN)", "value": value, "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "prewarm_s": head["prewarm_s"], "prewarm_steps": head["prewarm_steps"], "sustained": head.get("sustained"),
-        "config": {"workload": "C2: 2827->2048->2048->2048->257 ReLU+dropout(0.1/0.2), fp32, %d frames/GPU/step "
-                               "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
-                               % (BUNCH, BUNCH * world, chunk),
-                   "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world,
-                   "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if chosen == "rccl" else
-                                 "in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)") if dp else "none"),
-                   "launcher": "self (bench.py forked its ranks)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else
-                               ("torch.distributed.run" if world > 1 else "single process")},
-    }
-    if dp:
-        # north_star names RCCL; the library's default is its own peer kernels: ONE run answers which is faster here
-        res["exchange"] = {k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "value", "steps", "error", "dp_acquire_mode", "sustained")})
-                           for k, v in exchange.items()}
-        res["exchange"]["chosen"] = chosen
-        res["exchange"]["note"] = "every transport listed was attached by the whole group and timed with the same protocol in this run; value = the faster one"
-        res["ranks"] = head["ranks"]
-        res["distinct_devices"] = head["distinct_devices"]
-        res["dp_acquire_mode"] = head["dp_acquire_mode"]
-    if rank == 0:
-        res["step_frac_of_mfma_peak"] = flops_per_frame(LAYERS) * value / world / 1e12 / PEAK_MFMA_F32_TF
+        res = make_line(None, None, head=timed(None))
+    value = res["value"]
     if rank == 0 and not dp:
         # ---- roofline of the TIME-DOMINANT kernel: the grouped wgrad + fused momentum update of all layers
         # (bp_wgrad_dma<16,4,4,256>, LDS-DMA staged, one grouped launch per step, ~35 % of the step).  achieved = algorithmic FLOPs per launch (2*B*P: every layer's G = y^T.dEdX) / its average duration

@@ -116,3 +116,14 @@ def test_cpu_baseline_carries_the_c1_figure(oracle_mod):
     from oracle import oracle as O
     r = bench.cpu_baseline_c1(O, 2, frames=1280, budget_s=1.0)
     assert r["kind"] == "port" and r["unit"] == "frames/s" and r["value"] > 0 and "257->512->257" in r["sample"]
+
+
+def test_a_transport_that_hangs_does_not_cost_the_number_already_measured():
+    """RCCL's bootstrap has never run across devices here: if the second transport hangs inside a foreign call, a watchdog
+    thread prints the line from the transport already timed and ends every rank (a signal handler would never get to run)."""
+    import time
+    t0 = time.time()
+    j = _launch_check(extra_env={"BENCH_FAKE_HANG": "rccl:1", "BENCH_WATCHDOG_S": "3"})
+    ex = j["exchange"]
+    assert ex["chosen"] == "native" and "ms_per_step" in ex["native"] and "watchdog" in ex["rccl"]["error"]
+    assert time.time() - t0 < 60
