@@ -170,11 +170,7 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
         for (int u = 0; u < U; ++u) {
             const unsigned long long q = q0 + u * stride < n4 ? q0 + u * stride : q0;     // (clamped: loads stay unconditional)
             w[u] = *reinterpret_cast<const float4 *>(w_own + 4 * q);
-#if defined(BP_DEV) && defined(BP_DP_DELTA_NT)      // A/B: momentum state streamed past the caches (nobody else reads it)
-            { const bp_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const bp_f32x4 *>(d_own + 4 * q)); d[u] = make_float4(t.x, t.y, t.z, t.w); }
-#else
             d[u] = *reinterpret_cast<const float4 *>(d_own + 4 * q);
-#endif
 #pragma unroll
             for (int p = 0; p < BP_DP_MAXRANKS; ++p)
                 if (p < world) g[u][p] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg[p], (unsigned)(q * 16), 0, BP_AUX_SYS));
@@ -193,11 +189,7 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
             dn.y = a.mom * d[u].y - a.c1 * (s.y / a.ndiv + wc * w[u].y); wn.y = dn.y + 1.0f * w[u].y;
             dn.z = a.mom * d[u].z - a.c1 * (s.z / a.ndiv + wc * w[u].z); wn.z = dn.z + 1.0f * w[u].z;
             dn.w = a.mom * d[u].w - a.c1 * (s.w / a.ndiv + wc * w[u].w); wn.w = dn.w + 1.0f * w[u].w;
-#if defined(BP_DEV) && defined(BP_DP_DELTA_NT)
-            { const bp_f32x4 t = {dn.x, dn.y, dn.z, dn.w}; __builtin_nontemporal_store(t, reinterpret_cast<bp_f32x4 *>(d_own + 4 * q)); }
-#else
-            *reinterpret_cast<float4 *>(d_own + 4 * q) = dn;
-#endif
+            *reinterpret_cast<float4 *>(d_own + 4 * q) = dn;      // (nontemporal accesses for the momentum stream: 0.2657 vs 0.2537 ms, profiles/r05_dp_world1.txt)
 #pragma unroll
             for (int p = 0; p < BP_DP_MAXRANKS; ++p)
                 if (p < world)
