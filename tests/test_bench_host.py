@@ -127,3 +127,39 @@ def test_a_transport_that_hangs_does_not_cost_the_number_already_measured():
     ex = j["exchange"]
     assert ex["chosen"] == "native" and "ms_per_step" in ex["native"] and "watchdog" in ex["rccl"]["error"]
     assert time.time() - t0 < 60
+
+
+def test_live_counter_passes_are_parsed_into_traffic_and_mfma_busy_fraction(tmp_path, monkeypatch):
+    """bench.py measures its own HBM traffic and MFMA-busy fraction with rocprofv3 --pmc passes over itself.
+    A stand-in `rocprofv3` that writes the csv a real pass would write checks the plumbing: one pass per counter set, medians
+    per (kernel, grid), FETCH doubled and KB -> bytes, busy cycles over 4 x busy-CU cycles."""
+    import stat
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("""#!/usr/bin/env python3
+import os, sys
+a = sys.argv[1:]
+counters = a[a.index("--pmc") + 1:a.index("--output-format")]
+d = a[a.index("-d") + 1]
+os.makedirs(os.path.join(d, "host", "1"), exist_ok=True)
+vals = {"FETCH_SIZE": [92000.0, 92700.0, 92800.0], "WRITE_SIZE": [116000.0, 116800.0, 117000.0],
+        "SQ_VALU_MFMA_BUSY_CYCLES": [120.0e6, 120.0e6, 120.0e6], "SQ_BUSY_CU_CYCLES": [42.0e6, 43.0e6, 50.0e6]}
+with open(os.path.join(d, "host", "1", "p_counter_collection.csv"), "w") as f:
+    f.write("Kernel_Name,Grid_Size,Counter_Name,Counter_Value\\n")
+    for c in counters:
+        for v in vals[c]:
+            f.write('"void bp_wgrad_dma<16, 4, 4, 256, false>(MultiArgs)",933888,%s,%r\\n' % (c, v))
+            f.write('"void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>(GemmArgs, EpiArgs)",65536,%s,%r\\n' % (c, v / 4))
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    one = bench.live_pmc(["FETCH_SIZE"])
+    assert one["void bp_wgrad_dma<16, 4, 4, 256, false> grid=933888"]["FETCH_SIZE"] == 92700.0
+    lc = bench.live_counters()
+    assert lc["traffic_bytes"] == (2 * 92700.0 + 116800.0) * 1024.0
+    assert abs(lc["mfma_util"]["wgrad_update_grouped"]["mfma_busy_frac"] - 120.0e6 / (4 * 43.0e6)) < 1e-12
+    assert abs(lc["mfma_util"]["hidden_fwd_2048x2048"]["mfma_busy_frac"] - 30.0e6 / (4 * 10.75e6)) < 1e-12
+    # no profiler on the box: the line keeps the committed, source-stamped figures
+    monkeypatch.setenv("PATH", "/nonexistent")
+    monkeypatch.setattr(bench.os.path, "exists", lambda p: False if p.endswith("rocprofv3") else os.path.lexists(p))
+    assert bench.live_pmc(["FETCH_SIZE"]) is None
