@@ -1,5 +1,5 @@
 #!/bin/bash
-# copies the summaries of tools/profile_r05.sh (gpurun_out/prof_r05, scratch) into profiles/ (tracked)
+# copies the summaries of tools/profile_r05.sh (run through gpurun: `bash tools/profile_r05.sh`) (gpurun_out/prof_r05, scratch) into profiles/ (tracked)
 S=gpurun_out/prof_r05; D=profiles
 cp $(find $S/kt -name "*kernel_stats.csv" | head -1) $D/r05_bench_kernel_stats.csv
 cp $S/bench_under_rocprof.json $D/r05_bench_under_rocprof.json
