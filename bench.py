@@ -32,6 +32,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: needed for hipIpc across processes on this driver
+os.environ.setdefault("BP_DP_TIMEOUT_S", "120")            # attach / exchange time budget of the library (its default: 60 s)
 
 import numpy as np  # noqa: E402
 
@@ -598,6 +599,12 @@ def main():
     ndev = dnnse_amd.device_count()
     dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
+    if world > 1:
+        # the ranks of a fresh box can come out of their first `import torch` tens of seconds apart: meet here (host only, generous
+        # budget) so that they enter the group attach -- whose budget is the library's -- together
+        rv0 = dnnse_amd.Rendezvous(key + "-start", world, rank, timeout_s=900.0)
+        rv0.barrier()
+        rv0.close()
 
     W, b = dnnse_amd.glorot_net(LAYERS, seed=1, beta=0.5)    # Gen_rand_net flag=1, beta=0.5 recipe
     chunk = max(BUNCH, (args.chunk // BUNCH) * BUNCH)
