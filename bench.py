@@ -659,7 +659,8 @@ def main():
             for p in range(world):
                 pdev, pci, _tr, aq = g.dp_peer_info(p)
                 table.append({"rank": p, "device": pdev, "pci_bus_id": pci})
-            r.update(ranks=table, distinct_devices=len(set(x["pci_bus_id"] for x in table)), dp_acquire_mode=g.dp_peer_info(0)[3])
+            r.update(ranks=table, distinct_devices=len(set(x["pci_bus_id"] for x in table)), dp_acquire_mode=g.dp_peer_info(0)[3],
+                     dp_handoff="tile counters inside the wgrad launch" if g.dp_handoff() else "event + kernel boundary")
             dp_world, dp_rank, _ = g.dp_info()
             assert dp_world == world and dp_rank == rank
         # ---- sustained rate (an extra field, not `value`): the same steps for --sustained-s seconds, so that clocks, power and
@@ -712,7 +713,7 @@ def main():
         }
         if dp:
             # north_star names RCCL; the library's default is its own peer kernels: ONE run answers which is faster here
-            res["exchange"] = {k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "value", "steps", "error", "dp_acquire_mode", "sustained")})
+            res["exchange"] = {k: ({kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "value", "steps", "error", "dp_acquire_mode", "dp_handoff", "sustained")})
                                for k, v in exchange.items()}
             res["exchange"]["chosen"] = chosen
             res["exchange"]["note"] = "every transport listed was attached by the whole group and timed with the same protocol in this run; value = the faster one"

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "bp_fill_chunk_synthetic", "bp_train_resident", "bp_sync", "bp_grads_resident",
     "bp_grad_layout", "bp_grad_floats", "bp_read_grads", "bp_read_layer_output", "bp_last_train_ms", "bp_time_kernel",
     "bp_upload_chunk_windows", "bp_train_chunk_windows", "bp_cv_chunk_windows",
-    "bp_set_hyper", "bp_dp_attach", "bp_dp_attach_ex", "bp_dp_detach", "bp_dp_info", "bp_dp_peer_info", "bp_dp_barrier", "bp_dp_allgather",
+    "bp_set_hyper", "bp_dp_attach", "bp_dp_attach_ex", "bp_dp_detach", "bp_dp_info", "bp_dp_peer_info", "bp_dp_handoff", "bp_dp_barrier", "bp_dp_allgather",
     "bp_rdv_open", "bp_rdv_barrier", "bp_rdv_allgather", "bp_rdv_close", "bp_device_pci_bus_id", "bp_host_register", "bp_host_unregister",
     "bp_profile_step", "bp_measure_peaks", "bp_device_count", "bp_train_resident_masked", "bp_forward_windows",
 ]
@@ -110,6 +110,7 @@ def load_library(path=None):
     lib.bp_dp_attach.argtypes = [hp, C.c_int, C.c_int, C.c_char_p]
     lib.bp_dp_attach_ex.argtypes = [hp, C.c_int, C.c_int, C.c_char_p, C.c_int]
     lib.bp_dp_peer_info.argtypes = [hp, C.c_int, C.POINTER(C.c_int), C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.bp_dp_handoff.argtypes = [hp, C.POINTER(C.c_int)]
     lib.bp_dp_barrier.argtypes = [hp]
     lib.bp_dp_allgather.argtypes = [hp, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.bp_rdv_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
@@ -349,6 +350,13 @@ class BP_GPU(object):
         buf = C.create_string_buffer(32)
         self._check(self._lib.bp_dp_peer_info(self._h, int(peer), C.byref(dev), buf, 32, C.byref(tr), C.byref(aq)))
         return int(dev.value), buf.value.decode(), int(tr.value), int(aq.value)
+
+    def dp_handoff(self):
+        """True: gradient segments are handed to the exchange inside the running weight-gradient launch (tile counters);
+        False: event + kernel boundary per group of layers."""
+        v = C.c_int()
+        self._check(self._lib.bp_dp_handoff(self._h, C.byref(v)))
+        return bool(v.value)
 
     def dp_barrier(self):
         self._check(self._lib.bp_dp_barrier(self._h))

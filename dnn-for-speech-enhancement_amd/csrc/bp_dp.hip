@@ -591,6 +591,12 @@ extern "C" int bp_dp_peer_info(bp_handle *h, int peer, int *device, char *pci_bu
     if (acquire_mode) *acquire_mode = h->dp->acquire_mode;
     return BP_OK;
 }
+extern "C" int bp_dp_handoff(bp_handle *h, int *in_kernel)
+{
+    if (!h || !h->dp || !in_kernel) return fail(BP_ERR_STATE, "bp_dp_handoff: handle is not attached / null argument");
+    *in_kernel = h->dp->counters_ok && h->dp->backend != BP_DP_TRANSPORT_RCCL && step_wgrads_count(h) ? 1 : 0;
+    return BP_OK;
+}
 extern "C" int bp_dp_barrier(bp_handle *h)
 {
     if (!h || !h->dp) return fail(BP_ERR_STATE, "bp_dp_barrier: handle is not attached");

@@ -40,7 +40,7 @@ static uint32_t drop_threshold(float p)
 }
 
 extern "C" const char *bp_last_error(void) { return g_bp_err.c_str(); }
-extern "C" int bp_abi_version(void) { return 4; }   // 4: host-driven DP split removed; bp_rdv_*, bp_dp_attach_ex (RCCL transport), bp_dp_peer_info
+extern "C" int bp_abi_version(void) { return 5; }   // 4: host-driven DP split removed; bp_rdv_*, bp_dp_attach_ex (RCCL transport), bp_dp_peer_info; 5: bp_dp_handoff
 extern "C" const char *bp_build_target(void) { return "gfx950"; }
 extern "C" int bp_device_count(int *n)
 {

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, s), "missing export %s" % s
     assert sorted(pkg.ABI_SYMBOLS) == decl
     assert lib.bp_build_target() == b"gfx950"
-    assert lib.bp_abi_version() == 4
+    assert lib.bp_abi_version() == 5
 
 
 def test_config_struct_matches_header(pkg):

@@ -149,7 +149,26 @@ def test_attach_argument_errors(pkg):
     g.dp_attach(1, 0, "solo-%d" % os.getpid())            # a one-rank group is legal (exchange path, no peers)
     with pytest.raises(pkg.BPError):
         g.dp_attach(1, 0, "solo2-%d" % os.getpid())       # already attached
+    assert g.dp_handoff() is False                        # 4-frame bunches: not a shape the tile-counting launch is built for
     g.dp_detach()
+    g.close()
+
+
+def test_handoff_mode_is_reported(pkg):
+    """bp_dp_handoff: which hand-off of the gradient segments a group runs -- the first multi-GPU run must be able to say
+    whether the in-kernel tile counters survived the attach-time self-test on its devices or the event path carried it."""
+    from oracle import bp_numpy as N
+    ls = [70, 64, 33]
+    W, b = N.glorot_net(ls, seed=1, beta=1.0)
+    for B, transport, expect in ((128, 0, True), (128, 1, False), (96, 0, False)):
+        g = pkg.BP_GPU(1, 3, ls, B, 1.0, 0.5, 0.0, W, b, max_chunk_frames=2 * B)
+        g.dp_attach(1, 0, "handoff-%d-%d-%d" % (os.getpid(), B, transport), transport=transport)
+        assert g.dp_handoff() is expect, (B, transport)
+        g.dp_detach()
+        g.close()
+    g = pkg.BP_GPU(1, 3, ls, 128, 1.0, 0.5, 0.0, W, b, max_chunk_frames=256)
+    with pytest.raises(pkg.BPError):
+        g.dp_handoff()                                    # not attached
     g.close()
 
 
