@@ -409,13 +409,16 @@ static void dp_update_args(bp_handle *h, int l, DpReduceArgs &a)
 static int dp_update_grid(const DpReduceArgs &a, int layer)
 {
     const size_t n4 = (a.hi - a.lo) / 4;
-    int max_grid = 128;
+    // few, deep workgroups: at 2048 workgroups the exchange kernel crowds the GEMMs it runs beside out of the CUs'
+    // memory pipes (C2 step through the exchange path on one GPU: 0.51 ms at 2048, 0.34 at 512, 0.28 at 128, 0.31 at 64).
+    // Layer 1's update runs beside the second half of the weight-gradient launch (MFMA-bound, not a GEMM waiting on memory),
+    // and every later update and the next forward queue behind it: it takes more workgroups (round 5, same box: 0.2506-0.2508
+    // ms per step at 224 against 0.2540-0.2564 at 128; 160 / 192: 0.2517-0.2533; 256+: slower again)
+    int max_grid = layer == 1 ? 224 : 128;
 #ifdef BP_DEV
     max_grid = dev_int("BP_DP_GRID", max_grid);
     if (layer == 1) max_grid = dev_int("BP_DP_GRID1", max_grid);
 #endif
-    // few, deep workgroups: at 2048 workgroups the exchange kernel crowds the GEMMs it runs beside out of the CUs'
-    // memory pipes (C2 step through the exchange path on one GPU: 0.51 ms at 2048, 0.34 at 512, 0.28 at 128, 0.31 at 64)
     int grid = (int)((n4 + 256 * BP_DP_UNROLL - 1) / (256 * BP_DP_UNROLL));
     if (grid > max_grid) grid = max_grid;
     return grid < 1 ? 1 : grid;                                // (an empty slice still raises its flag)
