@@ -417,7 +417,8 @@ def run_exchanges(plan, attach, detach, timed, group_failed, guard=None):
     that hangs in its bootstrap must not cost the run the number it already has (the watchdog prints the line and ends the rank)."""
     out = {}
     for tr in plan:
-        cancel = guard(tr, dict(out)) if (guard and choose(out)) else None
+        have = choose(out) is not None
+        cancel = guard(tr, dict(out)) if (guard and have) else None
         try:
             err = attach(tr)                              # None, or this rank's error text
             n_failed = group_failed(tr, err)
@@ -428,6 +429,12 @@ def run_exchanges(plan, attach, detach, timed, group_failed, guard=None):
                 continue
             out[tr] = timed(tr)
             detach(tr, broken=False)
+        except Exception as e:                            # noqa: BLE001
+            # a later transport that RAISES (a timeout inside timed()/detach(), the verdict rendezvous) must not cost the run the
+            # number an earlier one already has; with nothing measured yet there is nothing to protect: propagate
+            if not have:
+                raise
+            out[tr] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             if cancel:
                 cancel()
@@ -511,11 +518,13 @@ def committed_mfma_util():
 
 
 def make_guard(rank, make_line):
-    """Watchdog around a further transport once one has been timed (run_exchanges): after BENCH_WATCHDOG_S seconds (default 240)
+    """Watchdog around a further transport once one has been timed (run_exchanges): after BENCH_WATCHDOG_S seconds (default 330:
+    clearly MORE than the library's attach budget BP_DP_TIMEOUT_S = 120 s plus the 120 s of the verdict rendezvous, so that a peer
+    that merely times out surfaces as an exception -- caught by run_exchanges -- and the watchdog is left for real hangs)
     rank 0 prints the line from what was measured before, every rank ends.  A thread, not a signal: the hang this is for sits
     inside a foreign call (a collective library's bootstrap), where Python never gets to run a signal handler."""
     import threading
-    limit = float(os.environ.get("BENCH_WATCHDOG_S", "240"))
+    limit = float(os.environ.get("BENCH_WATCHDOG_S", "330"))
 
     def guard(tr, out_so_far):
         def fire():
@@ -585,9 +594,15 @@ def main():
             if hang_spec.get(tr) == str(rank):
                 time.sleep(1e6)
             return "stand-in failure" if fail_spec.get(tr) == str(rank) else None
+        raise_spec = dict(x.split(":") for x in os.environ.get("BENCH_FAKE_RAISE", "").split(",") if ":" in x)   # "rccl:0": rank 0's timed region of rccl raises
+
+        def lc_timed(tr):
+            if raise_spec.get(tr) == str(rank):
+                raise RuntimeError("stand-in: exchange timed out on the device")
+            return {"ms_per_step": ms_spec.get(tr, 1.0), "steps": args.steps}
         ex, chosen = run_exchanges(plan, attach=lc_attach,
                                    detach=lambda tr, broken: log.append(("detach", tr, broken)),
-                                   timed=lambda tr: {"ms_per_step": ms_spec.get(tr, 1.0), "steps": args.steps},
+                                   timed=lc_timed,
                                    group_failed=group_failed, guard=make_guard(rank, lc_line))
         if rank == 0:
             print(json.dumps(lc_line(ex, chosen)), flush=True)

@@ -103,15 +103,19 @@ __global__ void bp_dp_sync(const unsigned *done, unsigned target, DpPeers peers,
 {
     const int p = threadIdx.x;
     const unsigned long long t0 = wall_clock64();
+    int ok = 1;
     if (p == 0 && done) {
         for (;;) {
             const unsigned v = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((int)(v - target) >= 0) break;
-            if (wall_clock64() - t0 > budget_ticks) { atomicExch(err, 4000u + 1u); break; }
+            if (wall_clock64() - t0 > budget_ticks) { atomicExch(err, 4000u + 1u); ok = 0; break; }
             __builtin_amdgcn_s_sleep(16);
         }
     }
     __builtin_amdgcn_s_barrier();          // (one wave: orders lane 0's poll in front of the other lanes' stores)
+    // the local segment never completed: do NOT tell the peers it is ready (they would reduce an incomplete segment before the
+    // error surfaces); their own waits time out and report this rank instead
+    if (!__builtin_amdgcn_readfirstlane(ok)) return;
     if (p < world) {
         __hip_atomic_store(peers.flags[p] + sig_index, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         for (;;) {

@@ -149,7 +149,9 @@ static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad
     float *sink = nullptr;
     HIPCHK(hipHostMalloc((void **)&cnt, 3 * sizeof(unsigned), hipHostMallocMapped));
     cnt[0] = cnt[1] = cnt[2] = 0u;
-    HIPCHK(hipMalloc((void **)&sink, 64));
+    if (hipMalloc((void **)&sink, 64) != hipSuccess) { (void)hipHostFree(cnt); return fail(BP_ERR_NOMEM, "hipMalloc (self-test sink)"); }
+    // inside the loop a HIP error leaves through `break` so that the tail below frees cnt / sink
+#define STK(x) { const hipError_t _e = (x); if (_e != hipSuccess) { rc = fail(BP_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(_e)); break; } }
     const DpPeers peers = dp_peers(d);
     DpReduceArgs a; memset(&a, 0, sizeof(a));
     for (int p = 0; p < d->world; ++p) { a.params[p] = d->p_probe_p[p]; a.grads[p] = d->p_probe_g[p]; }
@@ -160,7 +162,7 @@ static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad
         const unsigned ep = ep_base + (unsigned)r;             // flag values of the probe words only ever grow (fresh flag array per attach)
         // ---- (W): warm this device's caches with the OLD contents, let the peers overwrite, wait, re-read plainly
         hipLaunchKernelGGL(bp_dp_probe_touch, dim3(64), dim3(256), 0, h->stream, d->probe_p, sink);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        STK(hipStreamSynchronize(h->stream));
         if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }
         a.flag_index = bp_dp_flag_index(BP_DP_FLAG_PROBE, 0, d->rank); a.epoch = ep;
         hipLaunchKernelGGL(bp_dp_probe_push, dim3(1), dim3(256), 0, d->comm, a, (unsigned)r);
@@ -168,19 +170,19 @@ static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad
                            d->budget_ticks, d->err, 3u);
         if (d->acquire_mode) hipLaunchKernelGGL(bp_dp_l2_invalidate, dim3(64), dim3(64), 0, h->stream);
         hipLaunchKernelGGL(bp_dp_probe_check, dim3(64), dim3(256), 0, h->stream, d->probe_p, d->world, (unsigned)r, cnt);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(h->stream));
-        HIPCHK(hipStreamSynchronize(d->comm));
+        STK(hipGetLastError());
+        STK(hipStreamSynchronize(h->stream));
+        STK(hipStreamSynchronize(d->comm));
         // ---- (G): fill the fine-grained probe with plain stores, signal behind the kernel boundary, peers read it
         hipLaunchKernelGGL(bp_dp_probe_fill, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r, (unsigned)d->rank);
-        HIPCHK(hipEventRecord(d->ev_comm, h->stream));
-        HIPCHK(hipStreamWaitEvent(d->comm, d->ev_comm, 0));
+        STK(hipEventRecord(d->ev_comm, h->stream));
+        STK(hipStreamWaitEvent(d->comm, d->ev_comm, 0));
         hipLaunchKernelGGL(bp_dp_signal, dim3(1), dim3(64), 0, d->comm, peers, d->world, bp_dp_flag_index(BP_DP_FLAG_PROBE, 1, d->rank), ep);
         hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, d->comm, d->flags, bp_dp_flag_index(BP_DP_FLAG_PROBE, 1, 0), d->world, ep,
                            d->budget_ticks, d->err, 3u);
         hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r, cnt + 1);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(d->comm));
+        STK(hipGetLastError());
+        STK(hipStreamSynchronize(d->comm));
         if (*(volatile unsigned *)d->err) { rc = fail(BP_ERR_STATE, "data-parallel self-test: a peer's flag never arrived"); break; }
         if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }    // nobody refills a probe a peer still reads
         // ---- (C): the same direction with the step's IN-KERNEL hand-off -- the filling kernel counts its own workgroups, the
@@ -199,14 +201,15 @@ static int dp_selftest(bp_handle *h, int rounds, unsigned ep_base, unsigned *bad
                                    bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, d->rank), bp_dp_flag_index(BP_DP_FLAG_PROBE, 2, 0), ep2, short_budget, d->err, 3u);
                 hipLaunchKernelGGL(bp_dp_probe_check_remote, dim3(8), dim3(256), 0, d->comm, a, (unsigned)r + 100u, cnt + 2);
                 hipLaunchKernelGGL(bp_dp_probe_fill_count, dim3(64), dim3(256), 0, h->stream, d->probe_g, (unsigned)r + 100u, (unsigned)d->rank, d->done + BP_MAXLAYER);
-                HIPCHK(hipGetLastError());
-                HIPCHK(hipStreamSynchronize(h->stream));
-                HIPCHK(hipStreamSynchronize(d->comm));
+                STK(hipGetLastError());
+                STK(hipStreamSynchronize(h->stream));
+                STK(hipStreamSynchronize(d->comm));
                 if (*(volatile unsigned *)d->err) { *(volatile unsigned *)d->err = 0u; c_dead = true; cnt[2] += 1u; }
             }
             if (rdv_barrier(d->rdv) != 0) { rc = fail(BP_ERR_STATE, g_rdv_err); break; }
         }
     }
+#undef STK
     *bad_w = cnt[0]; *bad_g = cnt[1]; *bad_c = cnt[2];
     (void)hipHostFree(cnt); (void)hipFree(sink);
     return rc;
@@ -351,8 +354,11 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
         const int e = d->rccl.CommInitRank(&d->rccl_comm, world, id, rank);
         if (e != 0) { std::string m = std::string("ncclCommInitRank: ") + d->rccl.GetErrorString(e); dp_release(h, true); return fail(BP_ERR_DEVICE, m); }
         DK(hipMalloc((void **)&d->red, (max_slice + SLACK) * sizeof(float)));
-    } else if (world > 1) {
-        // ---- the memory-model contract of the native exchange, checked on these devices before anything relies on it
+    } else {
+        // ---- the memory-model contract of the native exchange, checked on these devices before anything relies on it.  A group of ONE
+        // rank runs it too: rounds (W) and (G) pass trivially there, round (C) finds out whether the two streams really run side by
+        // side -- where they do not (serialised dispatch under a counter-collecting profiler) the spinning bp_dp_sync queued in front
+        // of the kernel it waits for would run out its whole budget on every layer of every step.
         for (int mode = 0; mode < 2; ++mode) {
             d->acquire_mode = mode;
             unsigned bw = 0, bg = 0, bc = 0;
@@ -377,6 +383,9 @@ int dp_check(bp_handle *h)
 {
     if (h->dp && *(volatile unsigned *)h->dp->err) {
         const unsigned e = *(volatile unsigned *)h->dp->err;
+        if (e / 1000u == 4)
+            return fail(BP_ERR_STATE, "data-parallel exchange timed out on the device: this rank's weight-gradient tiles were never all counted "
+                                      "(exchange stream and main stream not running concurrently?)");
         return fail(BP_ERR_STATE, "data-parallel exchange timed out on the device: waiting for rank " + std::to_string((e % 1000u) - 1u) +
                                       (e / 1000u == 1 ? " (gradient ready)" : " (weights gathered)"));
     }

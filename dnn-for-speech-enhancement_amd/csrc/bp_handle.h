@@ -64,14 +64,13 @@ struct bp_handle {
     const uint8_t *inj_mask[BP_MAXLAYER];   // bp_train_resident_masked in progress: device masks of this bunch per layer output
     const float *inj_x0;                    // ... and the masked copy of its input rows
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
-    float *in, *in_drop, *targ, *out_dev;
+    float *in, *targ, *out_dev;
     float *slabs; size_t slab_stride; int out_splits;   // split-K workspace of the output layer
     float *grad; size_t grad_floats; size_t g_off[BP_MAXLAYER], g_cnt[BP_MAXLAYER];
     float *host_out;             // pinned staging for CV outputs (grow-only, whole chunk)
     float *out_chunk;            // device: network outputs of a whole chunk [frames][ld_L] (CV / forward), grow-only
     size_t out_chunk_frames;
     uint32_t step;               // bunches trained so far (dropout stream position)
-    long mask_lo, mask_hi; uint32_t mask_step0;
     uint32_t th_vis, th_hid;
     hipEvent_t ev0, ev1; float last_ms; int last_bunches;
     std::vector<void *> allocs;
@@ -132,8 +131,7 @@ hipError_t step_wgrads_store(bp_handle *h, const int *ls, int n, const float *x0
 bool step_wgrads_count(const bp_handle *h);
 unsigned step_wgrad_tiles(const bp_handle *h, int l);                                   // tiles of layer l in that launch
 hipError_t step_shadow(bp_handle *h, int l);                                            // fp32 master W_l -> bf16 shadow (bf16 mode)
-hipError_t step_mask_range(bp_handle *h, int first, int n);                             // visible-layer dropout of a range of a stacked chunk
-bool step_use_mask(const bp_handle *h);
+bool step_stages(const bp_handle *h);                                                   // the bunch's input rows go through the staged tile (window chunk | visible dropout)
 // single launches (bp_profile.hip: isolated kernel timing)
 hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y_prev, const float *targ, float *out, bool train, float alpha);
 hipError_t launch_dgrad(bp_handle *h, hipStream_t st, int l, int M);

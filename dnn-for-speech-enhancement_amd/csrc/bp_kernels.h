@@ -886,14 +886,41 @@ __global__ __launch_bounds__(256, K::MIN_WG) void bp_gemm_multi(const MultiArgs 
 struct StageArgs {
     float *x; int ld, width;                      // staged input tile [rows][ld], unpadded width
     const float *fea; int fea_dim, win;           // raw frames [n_frames][fea_dim]; win = context * fea_dim floats per window
-    const float *nat; const int *win_start, *nat_row;   // noise-aware rows; per-sample tables (already offset to the bunch's first sample)
+    const float *nat; const int *win_start, *nat_row;   // noise-aware rows; per-sample tables (already offset to the bunch's first sample); win_start == null: stacked rows (stage_rows_block)
     int rows; uint32_t thresh; int frame_off; uint32_t seed_lo, seed_hi, step;
     float *t; int ldt, twidth; const float *targ_frames; const int *targ_frame;   // staged targets (t may be null)
     int yb_in;                                    // column blocks of the input part; blocks by >= yb_in sweep the target columns
     int nbx;                                      // row blocks (rows / 4, rounded up): block (bx, by) of the flat index e is bx = e % nbx, by = e / nbx
 };
+// The same for a STACKED chunk (win_start == null: the caller handed rows that are already stacked, BP_GPU.cu:127-130): rows
+// r0..r0+3 of the bunch are copied as they lie, fea = first row of the bunch, fea_dim = its leading dimension (a multiple of 4
+// floats, rows 16-byte aligned), with the visible-layer dropout of BP_GPU.cu:536-539 applied on the way instead of in place in
+// the cached chunk.  One thread = 4 rows x 4 consecutive columns: four 16-byte loads, four Philox blocks (one per column, all
+// four words used), four 16-byte stores.
+__device__ __forceinline__ void stage_rows_block(const StageArgs &a, int bx, int by, int tx)
+{
+    const int r0 = bx * 4, c = (by * 256 + tx) * 4;
+    if (c >= a.ld) return;
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        v[j] = r0 + j < a.rows ? *reinterpret_cast<const float4 *>(a.fea + (size_t)(r0 + j) * a.fea_dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.thresh) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c + k >= a.width) break;
+            uint32_t w[4];
+            drop_words4(w, r0, c + k, a.frame_off, (uint32_t)a.width, 0u, a.step, a.seed_lo, a.seed_hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (w[j] < a.thresh) (&v[j].x)[k] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) *reinterpret_cast<float4 *>(a.x + (size_t)(r0 + j) * a.ld + c) = v[j];
+}
 __device__ __forceinline__ void stage_block(const StageArgs &a, int bx, int by, int tx)
 {
+    if (!a.win_start) { stage_rows_block(a, bx, by, tx); return; }
     const int r0 = bx * 4;
     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (by >= a.yb_in) {
@@ -925,38 +952,6 @@ __device__ __forceinline__ void stage_block(const StageArgs &a, int bx, int by, 
 __global__ __launch_bounds__(256) void bp_stage_bunch(const StageArgs a)
 {
     stage_block(a, blockIdx.x % a.nbx, blockIdx.x / a.nbx, threadIdx.x);
-}
-
-// Visible-layer dropout of the resident chunk (BP_GPU.cu:536-539 masks the device copy of the
-// chunk in place; here the masked frames go to a second buffer so the chunk stays reusable).
-// One thread = one unit x 4 consecutive chunk rows.
-__global__ void bp_mask_input(const float *in, float *out, int ld, int width, int first_frame, int n_frames,
-                              int bunch, int frame_off, uint32_t thresh, uint32_t seed_lo, uint32_t seed_hi,
-                              uint32_t step0)
-{
-    const int u = blockIdx.y * blockDim.x + threadIdx.x;     // unit blocks on grid.y (few), frame groups on grid.x (many)
-    const int g4 = blockIdx.x;
-    if (u >= ld) return;
-    uint32_t w[4]; uint64_t cur_blk = ~0ull; uint32_t cur_step = 0;
-    for (int j = 0; j < 4; ++j) {
-        const int rel = g4 * 4 + j;
-        if (rel >= n_frames) break;
-        const int f = first_frame + rel;
-        float v = in[(size_t)f * ld + u];
-        if (u < width) {
-            const uint32_t step = step0 + (uint32_t)(rel / bunch);
-            const uint64_t gf = (uint64_t)(uint32_t)(rel % bunch + frame_off);
-            const uint64_t blk = gf >> 2;
-            if (blk != cur_blk || step != cur_step) {
-                const uint64_t idx = blk * (uint64_t)(uint32_t)width + (uint32_t)u;
-                w[0] = (uint32_t)idx; w[1] = (uint32_t)(idx >> 32); w[2] = 0u; w[3] = step;
-                philox4x32_10(w[0], w[1], w[2], w[3], seed_lo, seed_hi);
-                cur_blk = blk; cur_step = step;
-            }
-            if (w[gf & 3] < thresh) v = 0.0f;
-        }
-        out[(size_t)f * ld + u] = v;
-    }
 }
 
 // Injected visible-layer mask (bp_train_resident_masked, parity tests): out[f][u] = mask[f][u] ? 0 : in[f][u]

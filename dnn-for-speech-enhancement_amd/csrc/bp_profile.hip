@@ -22,13 +22,14 @@ extern "C" int bp_profile_step(bp_handle *h, int first_frame, int n_bunches, flo
     HIPCHK(hipSetDevice(h->cfg.device));
     StepProf prof; prof.used = 0;
     int rc = BP_OK;
-    if (step_use_mask(h)) HIPCHK(step_mask_range(h, first_frame, n_bunches * h->B));
     h->prof = &prof;
     hipError_t er = prof_mark(h, -1);                        // origin
     for (int i = 0; er == hipSuccess && i < n_bunches; ++i) {
+        h->next_first = (step_stages(h) && i + 1 < n_bunches) ? first_frame + (i + 1) * h->B : -1;   // (as bp_train_resident)
         er = bunch(h, first_frame + i * h->B, true);
         h->step++;
     }
+    h->next_first = -1; h->pre.valid = false;
     h->prof = nullptr;
     if (er == hipSuccess) er = hipStreamSynchronize(h->stream);
     double sum[BP_PROF_KINDS] = {0}; long cnt[BP_PROF_KINDS] = {0};

@@ -86,6 +86,7 @@ extern "C" int bp_destroy(bp_handle *h)
 
 static int check_hyper(float, float, float, int, float, float, const char *);
 static int ensure_stacked(bp_handle *h);
+static int ensure_stage_tiles(bp_handle *h);
 static hipError_t stage_bunch(bp_handle *h, int first, int rows, bool train);
 static StageArgs stage_args(bp_handle *h, int first, int rows, bool train, int tile, uint32_t step);
 static int stage_blocks(const bp_handle *h, const StageArgs &a);
@@ -122,12 +123,12 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->cap = cfg->max_chunk_frames > 0 ? cfg->max_chunk_frames : BP_MAXCACHEFRAME;
     if (h->cap < h->B) h->cap = h->B;
     h->chunk_frames = 0;
-    h->step = 0; h->mask_lo = h->mask_hi = -1; h->mask_step0 = 0;
+    h->step = 0;
     h->th_vis = cfg->dropoutflag == 1 ? drop_threshold(cfg->visible_omit) : 0u;
     h->th_hid = cfg->dropoutflag == 1 ? drop_threshold(cfg->hid_omit) : 0u;
     for (int l = 0; l < h->L; ++l) { h->s[l] = cfg->layersizes[l]; h->ld[l] = pad64(h->s[l]); }
     h->own_stream = nullptr; h->host_out = nullptr; h->ev0 = h->ev1 = nullptr;
-    h->in = h->in_drop = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
+    h->in = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
     h->last_ms = 0.f; h->last_bunches = 0; h->dp = nullptr; h->params = h->deltas = nullptr;
     h->next_first = -1; h->pre.valid = false; h->wgen = 0; h->stage_cur = 0;
 
@@ -143,7 +144,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     HK(hipEventCreateWithFlags(&h->ev_wretired, hipEventDisableTiming));
     const int L = h->L;
     const size_t Bp = (size_t)((h->B + 63) & ~63);             // bunch rows rounded up to a whole tile
-    // (the stacked chunk buffers in / in_drop / targ are allocated by the first stacked upload, ensure_stacked():
+    // (the stacked chunk buffers in / targ are allocated by the first stacked upload, ensure_stacked():
     // a caller that only ever hands window chunks never pays for them)
     CK(dev_alloc(h, &h->out_dev, Bp * h->ld[L - 1]));
     // narrow output layer (e.g. 2048 -> 257): too few 32x32 tiles to fill 256 CUs, so its k range is
@@ -219,16 +220,14 @@ extern "C" int bp_set_hyper(bp_handle *h, float lrate, float momentum, float wei
     if (dropoutflag != h->cfg.dropoutflag || visible_omit != h->cfg.visible_omit || hid_omit != h->cfg.hid_omit) {
         HIPCHK(hipSetDevice(h->cfg.device));
         const uint32_t th_vis = dropoutflag == 1 ? drop_threshold(visible_omit) : 0u;
-        if (th_vis && h->in && !h->in_drop) {                   // (no stacked buffers yet: ensure_stacked allocates it with them)
-            HIPCHK(hipStreamSynchronize(h->stream));            // (an allocation in the middle of queued bunches: drain first)
-            r = dev_alloc(h, &h->in_drop, ((size_t)h->cap + 64) * h->ld[0]);
+        if (th_vis && h->in) {                                  // stacked chunk resident: its bunches are masked into the staged tile from now on
+            r = ensure_stage_tiles(h);
             if (r != BP_OK) return r;
         }
         h->cfg.dropoutflag = dropoutflag; h->cfg.visible_omit = visible_omit; h->cfg.hid_omit = hid_omit;
         h->th_vis = th_vis;
         h->pre.valid = false;                                   // (a pre-staged bunch was masked with the old rate)
         h->th_hid = dropoutflag == 1 ? drop_threshold(hid_omit) : 0u;
-        h->mask_lo = h->mask_hi = -1;
     }
     return BP_OK;
 }
@@ -294,8 +293,8 @@ hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y
         OutReduceArgs ra; memset(&ra, 0, sizeof(ra));
         ra.slabs = h->slabs; ra.slab_stride = h->slab_stride; ra.nsplit = h->out_splits; ra.M = M; ra.ld = cur; ra.n_true = h->s[l];
         ra.bias = h->b[l]; ra.alpha = alpha; ra.targ = targ; ra.scale = e.scale; ra.out = out; ra.dedx = train ? h->dx[l] : (float *)nullptr;
-        if (train && h->windows && h->next_first >= 0 && st == h->stream) {
-            // a window chunk with another bunch behind this one: stack (and mask, with the NEXT step's Philox position) that bunch
+        if (train && h->next_first >= 0 && st == h->stream) {
+            // another staged bunch behind this one (window chunk, or stacked chunk with visible dropout): stack / copy (and mask, with the NEXT step's Philox position) that bunch
             // into the other tile from the spare workgroups of this launch
             const int tile = 1 - h->stage_cur;
             const StageArgs sa = stage_args(h, h->next_first, h->B, true, tile, h->step + 1);
@@ -436,19 +435,11 @@ hipError_t launch_wgrad(bp_handle *h, hipStream_t st, int l, int M, const float 
     return run_wgrads(st, &p, 1);
 }
 
-// visible-layer dropout active: bunches read the masked copy of the chunk
-bool step_use_mask(const bp_handle *h) { return !h->windows && h->in_drop && h->th_vis; }
-
-hipError_t step_mask_range(bp_handle *h, int first, int n)
-{
-    if (!step_use_mask(h) || n <= 0) return hipSuccess;
-    dim3 grid((n + 3) / 4, (h->ld[0] + 255) / 256);
-    hipLaunchKernelGGL(bp_mask_input, grid, dim3(256), 0, h->stream, h->in, h->in_drop, h->ld[0], h->s[0], first, n,
-                       h->B, h->cfg.rank_frame_offset, h->th_vis, (uint32_t)h->cfg.seed,
-                       (uint32_t)(h->cfg.seed >> 32), h->step);
-    h->mask_lo = first; h->mask_hi = (long)first + n; h->mask_step0 = h->step;
-    return hipGetLastError();
-}
+// Bunches whose input rows go through the staged tile (x0s2): every bunch of a window chunk (stacked on the device, SURVEY 8f
+// N3) and, with visible-layer dropout on, every bunch of a STACKED chunk -- the mask of BP_GPU.cu:536-539 is applied while the
+// bunch's rows are copied into the L2-sized tile that the layer-1 forward and the layer-1 weight gradient both read.  The chunk
+// itself is never modified and no masked copy of it exists.
+bool step_stages(const bp_handle *h) { return h->windows || (h->th_vis != 0u && !h->inj_x0); }
 
 // ------------------------------------------------------------------ compute_dtype == 1 (bp_bf16.h)
 static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs)
@@ -640,11 +631,10 @@ hipError_t step_inputs(bp_handle *h, int first, const float **x0, const float **
     *x0 = h->in + (size_t)first * h->ld[0];
     *tg = h->targ + (size_t)first * h->ld[L - 1];
     if (h->inj_x0) *x0 = h->inj_x0;                     // bp_train_resident_masked: input rows with the injected visible mask
-    else if (step_use_mask(h)) {
-        const bool ok = h->mask_lo >= 0 && first >= h->mask_lo && first + B <= h->mask_hi &&
-                        (uint32_t)((first - h->mask_lo) / B) + h->mask_step0 == h->step && (first - h->mask_lo) % B == 0;
-        if (!ok) { const hipError_t er = step_mask_range(h, first, B); if (er != hipSuccess) return er; }
-        *x0 = h->in_drop + (size_t)first * h->ld[0];
+    else if (step_stages(h)) {                          // visible-layer dropout: the bunch's rows, masked, in the staged tile
+        const hipError_t er = stage_bunch(h, first, B, true);
+        *x0 = h->x0s;
+        return er;
     }
     return hipSuccess;
 }
@@ -740,7 +730,7 @@ extern "C" int bp_upload_chunk(bp_handle *h, int n_frames, const float *in, cons
         std::swap(h->targ, h->targ_alt);
     }
     h->chunk_frames = n_frames;
-    h->mask_lo = h->mask_hi = -1;
+    h->wgen++; h->pre.valid = false; h->next_first = -1;    // (a tile pre-staged from the old chunk is void)
     return BP_OK;
 }
 
@@ -768,8 +758,20 @@ static int ensure_stacked(bp_handle *h)
     int r;
     if (!h->in) { if ((r = dev_alloc(h, &h->in, capp * h->ld[0])) != BP_OK) return r; fresh = true; }
     if (!h->targ) { if ((r = dev_alloc(h, &h->targ, capp * h->ld[h->L - 1])) != BP_OK) return r; fresh = true; }
-    if (h->cfg.dropoutflag == 1 && h->th_vis && !h->in_drop) { if ((r = dev_alloc(h, &h->in_drop, capp * h->ld[0])) != BP_OK) return r; fresh = true; }
     if (fresh) HIPCHK(hipStreamSynchronize(h->stream));         // (dev_alloc zero-fills on the main stream)
+    return h->th_vis ? ensure_stage_tiles(h) : BP_OK;
+}
+
+// The two staged bunch tiles [Bp][ld_0] (+ target tiles for window chunks), on first need.
+static int ensure_stage_tiles(bp_handle *h)
+{
+    if (h->x0s) return BP_OK;
+    int r;
+    for (int k = 0; k < 2; ++k)
+        if ((r = dev_alloc(h, &h->x0s2[k], (size_t)h->Bp * h->ld[0])) != BP_OK || (r = dev_alloc(h, &h->tgs2[k], (size_t)h->Bp * h->ld[h->L - 1])) != BP_OK)
+            return r;
+    h->stage_cur = 0; h->x0s = h->x0s2[0]; h->tgs = h->tgs2[0];
+    HIPCHK(hipStreamSynchronize(h->stream));                    // (dev_alloc zero-fills on the main stream)
     return BP_OK;
 }
 
@@ -780,13 +782,21 @@ static StageArgs stage_args(bp_handle *h, int first, int rows, bool train, int t
     const int L = h->L, ld0 = h->ld[0], ldL = h->ld[L - 1];
     StageArgs a; memset(&a, 0, sizeof(a));
     a.x = h->x0s2[tile]; a.ld = ld0; a.width = h->s[0];
-    a.fea = h->wv.fea; a.fea_dim = h->wv.D; a.win = h->wv.win; a.nat = h->wv.nat;
-    a.win_start = h->wv.ws + first; a.nat_row = h->wv.nr ? h->wv.nr + first : (const int *)nullptr;
     a.rows = rows; a.thresh = train ? h->th_vis : 0u; a.frame_off = h->cfg.rank_frame_offset;
     a.seed_lo = (uint32_t)h->cfg.seed; a.seed_hi = (uint32_t)(h->cfg.seed >> 32); a.step = step;
+    a.nbx = (rows + 3) / 4;
+    if (!h->windows) {
+        // stacked chunk: rows [first, first+rows) as they lie (no tables: win_start == null selects the row-copy form, one thread =
+        // 4 rows x 4 columns), targets are read in place
+        a.fea = h->in + (size_t)first * ld0; a.fea_dim = ld0; a.win = h->s[0];
+        a.yb_in = (ld0 / 4 + 255) / 256;
+        return a;
+    }
+    a.fea = h->wv.fea; a.fea_dim = h->wv.D; a.win = h->wv.win; a.nat = h->wv.nat;
+    a.win_start = h->wv.ws + first; a.nat_row = h->wv.nr ? h->wv.nr + first : (const int *)nullptr;
     a.t = h->wv.tg ? h->tgs2[tile] : (float *)nullptr; a.ldt = ldL; a.twidth = h->s[L - 1];
     a.targ_frames = h->wv.tg; a.targ_frame = h->wv.tf ? h->wv.tf + first : (const int *)nullptr;
-    a.yb_in = (ld0 + 255) / 256; a.nbx = (rows + 3) / 4;
+    a.yb_in = (ld0 + 255) / 256;
     return a;
 }
 static int stage_blocks(const bp_handle *h, const StageArgs &a) { return a.nbx * (a.yb_in + (a.t ? (h->ld[h->L - 1] + 255) / 256 : 0)); }
@@ -829,14 +839,7 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
             return fail(BP_ERR_ARG, std::string(who) + ": nat_row out of range");
     }
     HIPCHK(hipSetDevice(h->cfg.device));
-    if (!h->x0s) {
-        int r;
-        for (int k = 0; k < 2; ++k)
-            if ((r = dev_alloc(h, &h->x0s2[k], (size_t)h->Bp * h->ld[0])) != BP_OK || (r = dev_alloc(h, &h->tgs2[k], (size_t)h->Bp * h->ld[L - 1])) != BP_OK)
-                return r;
-        h->stage_cur = 0; h->x0s = h->x0s2[0]; h->tgs = h->tgs2[0];
-        HIPCHK(hipStreamSynchronize(h->stream));                // (dev_alloc zero-fills on the main stream)
-    }
+    { const int r = ensure_stage_tiles(h); if (r != BP_OK) return r; }
     if (n > 0) {
         const size_t fea_b = (size_t)c->n_frames * D * 4, tg_b = with_targ ? (size_t)c->n_frames * sL * 4 : 0;
         const size_t nat_b = nat ? (size_t)c->n_nat * D * 4 : 0, idx_b = (size_t)n * 4;
@@ -875,7 +878,6 @@ static int upload_windows(bp_handle *h, const bp_window_chunk *c, bool with_targ
     h->windows = true;
     h->wgen++; h->pre.valid = false; h->next_first = -1;
     h->chunk_frames = n;
-    h->mask_lo = h->mask_hi = -1;
     return BP_OK;
 }
 
@@ -903,7 +905,7 @@ extern "C" int bp_fill_chunk_synthetic(bp_handle *h, int n_frames, uint64_t seed
         HIPCHK(hipGetLastError());
     }
     h->chunk_frames = n_frames;
-    h->mask_lo = h->mask_hi = -1;
+    h->wgen++; h->pre.valid = false; h->next_first = -1;
     return BP_OK;
 }
 
@@ -920,10 +922,9 @@ extern "C" int bp_train_resident(bp_handle *h, int first_frame, int n_frames)
     HIPCHK(hipSetDevice(h->cfg.device));
     const int nb = n_frames / h->B;          // partial last bunch ignored (BP_GPU.cu:315-318)
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    if (nb > 0 && step_use_mask(h)) HIPCHK(step_mask_range(h, first_frame, nb * h->B));
     hipError_t er = hipSuccess;
     for (int i = 0; i < nb && er == hipSuccess; ++i) {
-        h->next_first = (h->windows && !h->bf && i + 1 < nb) ? first_frame + (i + 1) * h->B : -1;
+        h->next_first = (step_stages(h) && !h->bf && i + 1 < nb) ? first_frame + (i + 1) * h->B : -1;
         er = h->dp ? dp_bunch(h, first_frame + i * h->B) : bunch(h, first_frame + i * h->B, true);
         if (er == hipSuccess) h->step++;
     }

@@ -219,8 +219,9 @@ int bp_dp_info(bp_handle *h, int *world, int *rank, unsigned *minibatches);
  * buffer of >= 16 bytes), plus this group's transport and acquire mode (0 kernel boundary, 1 explicit acquire). */
 int bp_dp_peer_info(bp_handle *h, int peer, int *device, char *pci_bus_id, int len, int *transport, int *acquire_mode);
 /* How this group hands a layer's gradient segment to the exchange: 1 = inside the running weight-gradient launch (its tiles
- * count themselves behind system-scope write-through stores; native transport, bunches of 128 / 256 / 512 frames, fp32),
- * 0 = event + kernel boundary per group of layers (RCCL, bf16, other bunch sizes, or a group whose attach-time self-test
+ * count themselves behind system-scope write-through stores; native transport, bunches of 128 / 256 / 512 frames, fp32, at most
+ * 4 weight layers = one grouped launch), 0 = event + kernel boundary per group of layers (RCCL, bf16, other bunch sizes, deeper
+ * nets, or a group -- of one rank too -- whose attach-time self-test
  * found that form unusable on its devices, e.g. streams that do not run concurrently).  The same on every rank. */
 int bp_dp_handoff(bp_handle *h, int *in_kernel);
 /* Host-side barrier / all-gather of one small record (<= 64 bytes) per rank over the group's rendezvous block, for

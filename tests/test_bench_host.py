@@ -129,6 +129,15 @@ def test_a_transport_that_hangs_does_not_cost_the_number_already_measured():
     assert time.time() - t0 < 60
 
 
+def test_a_transport_that_raises_does_not_cost_the_number_already_measured():
+    """the watchdog covers hangs only.  If the SECOND transport raises (a device-side exchange timeout surfacing in
+    its timed region, a rendezvous timeout) the first transport's number must still make the line (with nothing measured yet
+    run_exchanges re-raises: there is nothing to protect)."""
+    j = _launch_check(extra_env={"BENCH_FAKE_RAISE": "rccl:0"})
+    ex = j["exchange"]
+    assert ex["chosen"] == "native" and "ms_per_step" in ex["native"] and "stand-in" in ex["rccl"]["error"]
+
+
 def test_live_counter_passes_are_parsed_into_traffic_and_mfma_busy_fraction(tmp_path, monkeypatch):
     """bench.py measures its own HBM traffic and MFMA-busy fraction with rocprofv3 --pmc passes over itself.
     A stand-in `rocprofv3` that writes the csv a real pass would write checks the plumbing: one pass per counter set, medians

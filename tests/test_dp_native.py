@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from util import TOL, relerr
+from flip_accounting import K_FP64, fp64_bounded
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -59,7 +60,7 @@ def run_case(name, ls, B, world, nb, extra, timeout=600):
 
 
 @pytest.mark.parametrize("name,ls,B,world,nb,extra", CASES, ids=[c[0] for c in CASES])
-def test_native_dp_matches_global_bunch_oracle(oracle_mod, name, ls, B, world, nb, extra):
+def test_native_dp_matches_global_bunch_oracle(oracle_mod, parity_record, name, ls, B, world, nb, extra):
     c, (W, b, x, t), res = run_case(name, ls, B, world, nb, extra)
     L = len(ls)
     # 1. replicated state is bit-identical on every rank
@@ -86,13 +87,16 @@ def test_native_dp_matches_global_bunch_oracle(oracle_mod, name, ls, B, world, n
         o64 = oracle_mod.Oracle(ls, B * world, c.get("lr", 1.0), c.get("m", 0.5), c.get("wc", 0.0), W, b, acc_double=True, **kw)
         assert o64.train(x, t) == nb
         r64, r32 = o64.forward(x[:n_cv]).astype(np.float64), o.forward(x[:n_cv]).astype(np.float64)
-        assert np.abs(res[0]["out"] - r64).max() <= tol * np.abs(r64).max() + 4.0 * np.abs(r32 - r64).max(), (name, e_out)
+        parity_record(out_dist_to_fp64={"gpu": np.abs(res[0]["out"] - r64).max(), "fp32_oracle": np.abs(r32 - r64).max(), "max_fp64": np.abs(r64).max()})
+        assert fp64_bounded(np.abs(res[0]["out"] - r64).max(), np.abs(r32 - r64).max(), np.abs(r64).max(), tol), (name, e_out)
     worst = {}
     for l in range(1, L):
         for nm, a, ref in (("W", res[0]["W%d" % l], o.W[l]), ("b", res[0]["b%d" % l], o.b[l]),
                            ("dW", res[0]["dW%d" % l], o.dW[l]), ("db", res[0]["db%d" % l], o.db[l])):
             worst["%s%d" % (nm, l)] = relerr(a.reshape(np.asarray(ref).shape), ref)
     print(name, "rel.err vs global-bunch oracle:", {k: "%.2e" % v for k, v in worst.items()})
+    parity_record(case=name, world=world, local_bunch=B, steps=nb, out_vs_oracle=e_out, state_vs_global_bunch_oracle=dict(worst),
+                  bar="bf16 2e-2 (rms for the momentum state)" if bf else "plain 1e-4; fp64-bounded (K=%g) only for tensors listed under bounded_against_fp64" % K_FP64)
     if bf:   # bf16 gradients: single elements move by per cents of the largest one with the summation order; rms criterion
         from test_gpu_parity import relerr_rms     # (same bar as tests/test_gpu_parity.py::test_bf16_step_matches_bf16_oracle)
         for l in range(1, L):
@@ -104,11 +108,12 @@ def test_native_dp_matches_global_bunch_oracle(oracle_mod, name, ls, B, world, n
     # pre-activations per bunch lies within rounding of 0, and whether its ReLU is on decides one frame's contribution
     # to a whole column of G (seen as ~1e-2 of max|delta|, ~2e-4 of max|W|) under ANY summation order, the
     # reference's own included.  For exactly the tensors that miss the plain bar, by name, the bar is the fp64-accumulated
-    # oracle: as close to it as the fp32 restatement of the reference is (x4).  Small nets must meet the plain bar.
+    # oracle: at most K_FP64 (= 2, tests/flip_accounting.py says why) times as far from it as the fp32 restatement of the reference is.  Small nets must meet the plain bar.
     assert not bad or max(ls) >= 1024, (name, bad)
     if bad:
         o64 = oracle_mod.Oracle(ls, B * world, c.get("lr", 1.0), c.get("m", 0.5), c.get("wc", 0.0), W, b, acc_double=True, **kw)
         assert o64.train(x, t) == nb
+        bounded = {}
         for k in bad:
             l = int(k[-1])
             a = res[0][k]
@@ -117,7 +122,9 @@ def test_native_dp_matches_global_bunch_oracle(oracle_mod, name, ls, B, world, n
             ea = np.abs(np.asarray(a, np.float64).reshape(r64.shape) - r64).max()
             e32 = np.abs(np.asarray(r32, np.float64) - r64).max()
             print("  %s: |gpu-fp64| %.3e, |fp32 oracle-fp64| %.3e, max|fp64| %.3e" % (k, ea, e32, np.abs(r64).max()))
-            assert ea <= tol * np.abs(r64).max() + 4.0 * e32, (name, k, ea, e32)
+            bounded[k] = {"gpu_to_fp64": ea, "fp32_oracle_to_fp64": e32, "max_fp64": np.abs(r64).max(), "ratio": ea / max(e32, 1e-300)}
+            assert fp64_bounded(ea, e32, np.abs(r64).max(), tol), (name, k, ea, e32)
+        parity_record(bounded_against_fp64=bounded)
     co = o.crossvalid(x[:n_cv], t[:n_cv])
     assert abs(float(res[0]["cv"]) - co) < (5e-2 if bf else TOL) * abs(co)
     # 3. STRICT check with no escape hatch: the same library on ONE rank with the whole global bunch.  Forward and dgrad
@@ -133,6 +140,7 @@ def test_native_dp_matches_global_bunch_oracle(oracle_mod, name, ls, B, world, n
             n = min(res[0][k].shape[0], one[0][k].shape[0]) if k == "out" else None
             strict[k] = relerr(res[0][k][:n], one[0][k][:n]) if k == "out" else relerr(res[0][k], one[0][k])
         print(name, "sharded vs one rank with the global bunch:", {k: "%.1e" % v for k, v in strict.items()})
+        parity_record(sharded_vs_one_rank_same_library=strict, strict_bar=1e-5)
         for k, v in strict.items():
             assert v < 1e-5, (name, "sharded run differs from the unsharded run of the same library", k, v)
 
@@ -172,7 +180,7 @@ def test_handoff_mode_is_reported(pkg):
     g.close()
 
 
-def test_config5_shape_8_ranks_bf16_equals_single_device(oracle_mod):
+def test_config5_shape_8_ranks_bf16_equals_single_device(oracle_mod, parity_record):
     """BASELINE.json configs[4] at its real shape: 2827->4096x5->257, bf16 operands / fp32 master weights, global minibatch
     4096 = 8 ranks x 512 frames (8 processes sharing the GPU).  Two checkers: (1) the bf16 oracle trained on the GLOBAL
     4096-frame minibatch (15 s on 8 cores) -- outputs of the trained net, weights and biases within the bf16 tolerance
@@ -206,6 +214,8 @@ def test_config5_shape_8_ranks_bf16_equals_single_device(oracle_mod):
         a, ref = (res8[0][k][:n_out], res1[0][k][:n_out]) if k == "out" else (res8[0][k], res1[0][k])
         worst[k] = relerr(a, ref)
     print("c5 8x512 vs 1x4096:", {k: "%.1e" % v for k, v in worst.items()})
+    parity_record(config="C5 8 ranks x 512, bf16", vs_bf16_oracle_global_minibatch=vs_oracle, vs_single_device_4096=worst,
+                  bar="2e-2 (5e-2 rms for the momentum state)")
     for k, v in worst.items():
         if k.startswith(("W", "b")) or k == "out":
             assert v < 2e-2, (k, v)

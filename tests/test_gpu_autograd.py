@@ -24,7 +24,7 @@ def _mk(pkg, ls, B, W, b, **kw):
 
 
 @pytest.mark.parametrize("ls,drop", [(C2, True), (C3, False)])
-def test_full_size_gradient_matches_torch_float64_autograd(pkg, ls, drop):
+def test_full_size_gradient_matches_torch_float64_autograd(pkg, parity_record, ls, drop):
     pytest.importorskip("torch")
     B, L, seed = 256, len(ls), 31
     W, b = pkg.glorot_net(ls, seed=1, beta=0.5)                      # the bench's init recipe (product code, not oracle/)
@@ -69,10 +69,12 @@ def test_full_size_gradient_matches_torch_float64_autograd(pkg, ls, drop):
             bg = bg - dx_g[l].sum(0)
         worst["W%d" % l], worst["b%d" % l] = relerr(Gg, tw[l]), relerr(bg, tb[l])
     print("gradient vs torch float64 autograd (frames %s removed):" % rows, {k: "%.1e" % v for k, v in worst.items()})
+    parity_record(config="C2" if drop else "C3", reference="torch float64 autograd + numpy Philox (nothing from oracle/)",
+                  flips=[list(f) for f in fl], gradient_vs_torch_float64=worst, bar="plain 1e-4 with the differing frames removed from both sides")
     assert all(v < TOL for v in worst.values()), worst
 
 
-def test_bf16_gradient_matches_an_oracle_free_bf16_reference(pkg):
+def test_bf16_gradient_matches_an_oracle_free_bf16_reference(pkg, parity_record):
     """compute_dtype = 1 (bf16 GEMM operands, fp32 accumulation; BASELINE.json configs[4]'s arithmetic) at bf16's bar of 2e-2
     against a reference that shares nothing with oracle/: the bunch written out by hand in numpy float64 with bf16 rounding at
     the points where the device stores bf16 (tests/torch_ref.py bf16_grads; pinned on the CPU against the oracle's bf16 mode).
@@ -102,5 +104,6 @@ def test_bf16_gradient_matches_an_oracle_free_bf16_reference(pkg):
         exact["W%d" % l] = rms(gw[l], tw[l])
     print("bf16 gradient vs the hand-written bf16 reference (rms):", {k: "%.1e" % v for k, v in worst.items()})
     print("bf16 gradient vs exact arithmetic, torch float64 autograd (rms):", {k: "%.1e" % v for k, v in exact.items()})
+    parity_record(gradient_rms_vs_handwritten_bf16_reference=worst, gradient_rms_vs_exact_arithmetic=exact, bar="2e-2 rms")
     assert all(v < 2e-2 for v in worst.values()), worst
     assert all(1e-4 < v < 0.15 for v in exact.values()), exact      # it really is a bf16 computation, and not a broken one

@@ -191,11 +191,11 @@ C2 = [257 * 11, 2048, 2048, 2048, 257]
 C3 = [257 * 12, 2048, 2048, 2048, 257]          # 11 frames + the appended noise-estimate block (NAT)
 
 
-from flip_accounting import backprop_rows, relu_flips  # noqa: E402  (shared with test_gpu_autograd.py)
+from flip_accounting import K_FP64, backprop_rows, fp64_bounded, relu_flips  # noqa: E402  (shared with test_gpu_autograd.py)
 
 
 @pytest.mark.parametrize("ls,drop", [(C2, True), (C3, False)])
-def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
+def test_full_size_config_matches_oracle(pkg, oracle_mod, parity_record, ls, drop):
     """C2 / C3 at their real sizes (256-frame bunch) against the oracle at the PLAIN 1e-4 of north_star, with the one
     effect that can legitimately break it made explicit and counted instead of being absorbed by a looser bound:
     a hidden pre-activation that lies within fp32 rounding of zero gets its ReLU decision from the GEMM's summation
@@ -205,7 +205,9 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
     the oracle's, asserts that there are only a handful and that each is within a few rounding errors of zero, and then
     asserts plain 1e-4 on the gradient with exactly those frames' contributions removed on both sides, (3) trains two
     steps and demands plain 1e-4 on every state tensor and on the trained net's outputs whenever no decision differed;
-    when one did, the two trajectories are both correct fp32 trajectories and the bound is the fp64-accumulated one."""
+    when one did, the two trajectories are both correct fp32 trajectories and the yardstick is the fp64-accumulated one:
+    the device at most K_FP64 (= 2, tests/flip_accounting.py) times as far from it as the reference-order fp32 restatement --
+    measured: 1e-5 ... 2e-3 times as far.  The hatch-free counterpart at small lrate is the ten-step test below."""
     torch = pytest.importorskip("torch")
     B, L = 256, len(ls)
     W, b = N.glorot_net(ls, seed=1, beta=0.5)                       # the bench's init recipe
@@ -227,11 +229,14 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
             h64 = torch.clamp(h64, min=0.0)
     e_t = relerr(og, h64.numpy())
     print("pure forward vs torch float64: %.2e" % e_t)
+    parity_record(config="C2" if drop else "C3", lrate=1.0, steps=2, pure_forward_vs_fp32_oracle=relerr(og, o.forward(x[:300])),
+                  pure_forward_vs_torch_float64=e_t)
     assert e_t < TOL
     # ---- (2) + (3): two training steps; before each, that bunch's gradient from the device with the ReLU decisions counted
     g.upload_chunk(x, t)
-    flips = []
+    flips, grad_err = [], {}
     for i in range(2):
+        step_err = {}
         xb, tb = x[i * B:(i + 1) * B], t[i * B:(i + 1) * B]
         Wc = [None] + [wl.copy() for wl in o.W[1:]]                  # the oracle's current weights (the device's differ by ~1e-7)
         bc = [None] + [v.copy() for v in o.b[1:]]
@@ -262,10 +267,12 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
                 bg_ = bg_ - dx_g[l].sum(0); bo_ = bo_ - dx_o[l].sum(0)
             eg, eb = relerr(Gg, Go), np.abs(bg_ - bo_).max() / max(np.abs(bo_).max(), 1e-30)
             print("  bunch %d layer %d gradient (differing frames %s removed): W %.2e  b %.2e" % (i, l, rows, eg, eb))
+            step_err["G%d" % l], step_err["gb%d" % l] = eg, eb
             # step 0 starts from identical weights: plain 1e-4.  At step 1 a flip of step 0 has already moved the two
             # weight sets apart (by design of the effect), so the plain bar is only owed while nothing has flipped
             assert (eg < TOL and eb < TOL) or (i > 0 and flips), (i, l, eg, eb)
         flips += [(i,) + f for f in fl]
+        grad_err["bunch%d" % i] = step_err
         g.train_resident(i * B, B)
         o.train_bunch(xb, tb); o64.train_bunch(xb, tb)
     w, bb = g.get_weights()
@@ -276,8 +283,12 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
     print("forward output after 2 steps: rel.err vs fp32 oracle %.2e (fp32 oracle vs fp64-accumulated oracle: %.2e)" % (e_out, e_ref))
     diverged = len(flips) > 0 or e_ref >= TOL      # (e_ref: the oracle's own two summation orders disagree -- a flip between THEM)
     print("differing ReLU decisions over the two steps: %d -> %s bar" % (len(flips), "fp64-bounded" if diverged else "plain 1e-4"))
-    assert e_out < TOL or (diverged and np.abs(og.astype(np.float64) - o64f).max() <= TOL * np.abs(o64f).max() + 4.0 * np.abs(o32f.astype(np.float64) - o64f).max()), (e_out, e_ref, flips)
-    worst, bounded = {}, []
+    ea_out, e32_out = np.abs(og.astype(np.float64) - o64f).max(), np.abs(o32f.astype(np.float64) - o64f).max()
+    rec = dict(flips=[list(f) for f in flips], gradient_err_flipped_frames_removed=grad_err, out_vs_fp32_oracle=e_out,
+               fp32_oracle_vs_fp64_oracle_out=e_ref, bar="fp64-bounded" if diverged else "plain 1e-4", K_FP64=K_FP64,
+               out_dist_to_fp64={"gpu": ea_out, "fp32_oracle": e32_out, "max_fp64": float(np.abs(o64f).max())})
+    assert e_out < TOL or (diverged and fp64_bounded(ea_out, e32_out, np.abs(o64f).max())), (e_out, e_ref, flips)
+    worst, bounded = {}, {}
     for l in range(1, L):
         for nm, a, r32, r64 in (("W", w[l], o.W[l], o64.W[l]), ("b", bb[l], o.b[l], o64.b[l]),
                                 ("dW", dw[l], o.dW[l], o64.dW[l]), ("db", dbb[l], o.db[l], o64.db[l])):
@@ -286,11 +297,113 @@ def test_full_size_config_matches_oracle(pkg, oracle_mod, ls, drop):
             if not e < TOL:
                 ea = np.abs(np.asarray(a, np.float64) - r64).max()
                 e32 = np.abs(np.asarray(r32, np.float64) - r64).max()
-                bounded.append("%s%d" % (nm, l))
+                bounded["%s%d" % (nm, l)] = {"gpu_to_fp64": ea, "fp32_oracle_to_fp64": e32, "max_fp64": float(np.abs(r64).max()),
+                                             "ratio": ea / max(e32, 1e-300)}
                 # only legitimate when a ReLU decision differed somewhere (counted above, or between the oracle's own two orders)
                 assert diverged, ("no ReLU decision differed, yet a state tensor misses the plain bar", nm, l, e)
-                assert ea <= TOL * np.abs(r64).max() + 4.0 * e32, (nm, l, e, ea, e32)
+                assert fp64_bounded(ea, e32, np.abs(r64).max()), (nm, l, e, ea, e32)
     print("rel.err vs fp32 oracle:", {k: "%.1e" % v for k, v in worst.items()}, "| bounded against fp64 instead:", bounded)
+    parity_record(state_vs_fp32_oracle=worst, bounded_against_fp64=bounded, **rec)
+    g.close()
+
+
+@pytest.mark.parametrize("ls,drop", [(C2, True), (C3, False)], ids=["C2", "C3"])
+def test_full_size_ten_steps_small_lrate_plain_bar(pkg, oracle_mod, parity_record, ls, drop):
+    """C2 / C3 at their real sizes, TEN steps, lrate 0.02, momentum 0.5, the product's own Philox masks -- against the fp32
+    oracle at PLAIN 1e-4 with no fp64 fallback.  With a small learning rate a ReLU decision that
+    falls differently (a pre-activation within rounding of zero, summation order decides) cannot cascade through the
+    weights: the trained net's OUTPUTS and the weight matrices meet the plain bar raw, whatever happened (asserted).
+    The momentum state is different in kind: it is the m^k-weighted SUM of the last steps' gradients, so ONE frame with a
+    differing decision moves a whole column of it by ~1/16 of the column (1 of 256 frames, random signs) INDEPENDENTLY of
+    lrate -- and so is the bias vector of this init recipe, which starts at zero and therefore consists of nothing but
+    accumulated updates.  That effect is not absorbed by a looser bound: the test counts every differing decision of every
+    step (each asserted to lie within rounding of zero), computes in fp64 what exactly those frames contribute to each
+    side's gradient from that side's own activations, carries both through the update recursion (delta <- m*delta - c1*G/n;
+    W <- W + delta: DevFunc.cu:313-318, 270-277 -- linear maps), subtracts them, and then demands plain 1e-4 on dW / db /
+    b (and W) as well.  When no decision differed anywhere the comparison is the raw one.  All numbers go to the parity JSON."""
+    B, L, NS, lr, m = 256, len(ls), 10, 0.02, 0.5
+    W, b = N.glorot_net(ls, seed=1, beta=0.5)
+    rng = np.random.default_rng(20261001)
+    x = rng.standard_normal((NS * B, ls[0]), dtype=np.float32)
+    t = rng.standard_normal((NS * B, ls[-1]), dtype=np.float32)
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=31) if drop else {}
+    g = _mk(pkg, ls, B, W, b, lr=lr, m=m, cap=NS * B, **kw)
+    o = oracle_mod.Oracle(ls, B, lr, m, 0.0, W, b, **kw)
+    g.upload_chunk(x, t)
+    c1 = (1.0 - m) * lr
+    # per side: what the frames with a differing decision have contributed to the momentum state (dW, db) and, summed over the
+    # steps, to the parameters (sW, sb); allocated on the first differing decision
+    corr = {s: None for s in ("g", "o")}
+    flips, per_step = [], []
+    for i in range(NS):
+        xb, tb = x[i * B:(i + 1) * B], t[i * B:(i + 1) * B]
+        Wc = [None] + [wl.copy() for wl in o.W[1:]]
+        bc = [None] + [v.copy() for v in o.b[1:]]
+        g.grads_resident(i * B)                                      # forward + backward at the step's Philox position, state untouched
+        ys_g = [None] + [g.read_layer_output(l) for l in range(1, L - 1)]
+        masks = [o.fill_mask(i, l, B) for l in range(L - 1)] if drop else None
+        _, _, ys_o, out_o = o.grads(xb, tb, masks=masks)
+        ys_g[0] = ys_o[0]
+        fl = []
+        for l in range(1, L - 1):
+            fl += [(l,) + f for f in relu_flips(ys_g[l], ys_o[l], ys_g[l - 1], Wc[l], bc[l])]
+        for l, f, n, mag, scale in fl:
+            assert mag <= 64.0 * scale, ("a differing ReLU decision that is NOT within rounding of zero", i, l, f, n, mag, scale)
+        assert len(fl) <= 8, (i, fl)
+        rows = sorted(set(f for _, f, _, _, _ in fl))
+        for side, ys in (("g", ys_g), ("o", ys_o)):
+            if corr[side] is None:
+                if not rows:
+                    continue
+                corr[side] = {k: [None] + [np.zeros((ls[l - 1], ls[l]) if k[1] == "W" else ls[l]) for l in range(1, L)] for k in ("dW", "db", "sW", "sb")}
+            c = corr[side]
+            if rows:
+                if side == "g":                                      # the device's training-mode output of those frames, from ITS hidden outputs
+                    out_full = np.zeros((B, ls[-1]))
+                    out_full[rows] = ys_g[L - 2][rows].astype(np.float64) @ Wc[L - 1].astype(np.float64) + bc[L - 1].astype(np.float64)
+                else:
+                    out_full = out_o
+                dx = backprop_rows(ls, Wc, ys, out_full, tb, rows, B)
+            for l in range(1, L):
+                c["dW"][l] *= m; c["db"][l] *= m
+                if rows:
+                    c["dW"][l] -= c1 * (ys[l - 1][rows].astype(np.float64).T @ dx[l]) / B
+                    c["db"][l] -= c1 * dx[l].sum(0) / B
+                c["sW"][l] += c["dW"][l]; c["sb"][l] += c["db"][l]
+        flips += [(i,) + f for f in fl]
+        per_step.append(len(fl))
+        g.train_resident(i * B, B)
+        o.train_bunch(xb, tb)
+    print("differing ReLU decisions per step:", per_step, [(i, l, f, n, "%.1e" % mag, "%.1e" % sc) for i, l, f, n, mag, sc in flips])
+    w, bb = g.get_weights()
+    dw, dbb = g.get_deltas()
+    xf = rng.standard_normal((300, ls[0]), dtype=np.float32)
+    e_out = relerr(g.forward(xf), o.forward(xf))
+    raw, removed, update = {"out": e_out}, {}, {}
+    for l in range(1, L):
+        dev = {"W": w[l], "b": bb[l], "dW": dw[l], "db": dbb[l]}
+        ora = {"W": o.W[l], "b": o.b[l], "dW": o.dW[l], "db": o.db[l]}
+        for nm in ("W", "b", "dW", "db"):
+            raw["%s%d" % (nm, l)] = relerr(dev[nm], ora[nm])
+            if corr["g"] is not None:
+                ck = {"W": "sW", "b": "sb", "dW": "dW", "db": "db"}[nm]
+                removed["%s%d" % (nm, l)] = relerr(dev[nm] - corr["g"][ck][l], ora[nm] - corr["o"][ck][l])
+        # the accumulated UPDATE of the weight matrix on its own (recorded, not asserted: W - W0 cancels 2-3 digits in fp32)
+        ug, uo = w[l].astype(np.float64) - W[l], o.W[l].astype(np.float64) - W[l]
+        update["W%d_raw" % l] = relerr(ug, uo)
+        if corr["g"] is not None:
+            update["W%d_removed" % l] = relerr(ug - corr["g"]["sW"][l], uo - corr["o"]["sW"][l])
+    print("10 steps, lrate %.2f: rel.err vs fp32 oracle (raw):" % lr, {k: "%.1e" % v for k, v in raw.items()})
+    print("  with the differing frames' contributions removed from both sides:", {k: "%.1e" % v for k, v in removed.items()})
+    parity_record(config="C2" if drop else "C3", lrate=lr, momentum=m, steps=NS, flips_per_step=per_step,
+                  flips=[list(f) for f in flips], raw_vs_fp32_oracle=raw, flipped_frames_removed=removed,
+                  weight_update_vs_fp32_oracle=update, bar="plain 1e-4, no fp64 fallback: outputs and W raw; b, dW, db raw when no ReLU "
+                  "decision differed, else with exactly the differing frames' contributions removed from both sides")
+    assert e_out < TOL, e_out
+    for l in range(1, L):
+        assert raw["W%d" % l] < TOL, (l, raw)
+        for k in ("b%d" % l, "dW%d" % l, "db%d" % l):
+            assert raw[k] < TOL or (flips and removed[k] < TOL), (k, raw[k], removed.get(k), per_step)
     g.close()
 
 
@@ -489,7 +602,7 @@ BF_CASES = [
 
 
 @pytest.mark.parametrize("ls,B,nb,act,rule,wc,drop", BF_CASES)
-def test_bf16_step_matches_bf16_oracle(pkg, oracle_mod, ls, B, nb, act, rule, wc, drop):
+def test_bf16_step_matches_bf16_oracle(pkg, oracle_mod, parity_record, ls, B, nb, act, rule, wc, drop):
     W, b = N.glorot_net(ls, seed=6, beta=1.0)
     rng = np.random.default_rng(23)
     b = [None] + [rng.normal(size=ls[l]).astype(np.float32) * 0.1 for l in range(1, len(ls))]
@@ -509,6 +622,9 @@ def test_bf16_step_matches_bf16_oracle(pkg, oracle_mod, ls, B, nb, act, rule, wc
     assert o.train(x, t) == nb
     w, bb = g.get_weights()
     dw, dbb = g.get_deltas()
+    parity_record(forward_vs_bf16_oracle=relerr(f_g, f_o), bf16_oracle_vs_fp32_oracle=relerr(f_o, f_32),
+                  W={l: relerr(w[l], o.W[l]) for l in range(1, len(ls))}, dW_rms={l: relerr_rms(dw[l], o.dW[l]) for l in range(1, len(ls))},
+                  bar="W, b 5e-3; momentum state 2e-2 rms")
     for l in range(1, len(ls)):
         assert relerr(w[l], o.W[l]) < TOL_BF16 / 4, ("W", l, relerr(w[l], o.W[l]))
         assert relerr(bb[l], o.b[l]) < TOL_BF16 / 4, ("b", l)
@@ -540,7 +656,7 @@ def test_bf16_gradient_buffer_equals_fused_step(pkg):
     g1.close(); g2.close()
 
 
-def test_bf16_config5_shape_one_step(pkg, oracle_mod):
+def test_bf16_config5_shape_one_step(pkg, oracle_mod, parity_record):
     """BASELINE.json configs[4] per-GPU shape: 2827 -> 4096 x 5 -> 257, 512 frames, ReLU, no dropout; one step.
     At this depth and width two correct bf16 implementations that only differ in summation order already disagree by
     2-3 % (rms) on the back-propagated gradients (rounding / ReLU boundaries falling differently compound over five
@@ -554,14 +670,19 @@ def test_bf16_config5_shape_one_step(pkg, oracle_mod):
     g = _mk(pkg, ls, B, W, b, lr=1.0, cap=B, compute_dtype=1)
     o = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, compute_dtype=1)
     od = oracle_mod.Oracle(ls, B, 1.0, 0.5, 0.0, W, b, compute_dtype=1, acc_double=True)
-    assert relerr(g.forward(x), o.forward(x)) < TOL_BF16
+    e_fwd = relerr(g.forward(x), o.forward(x))
+    assert e_fwd < TOL_BF16
     g.train(B, x, t)
     o.train(x, t)
     od.train(x, t)
     dw, dbb = g.get_deltas()
     w, bb = g.get_weights()
+    rec = {}
     for l in range(1, len(ls)):
         spread_w, spread_b = relerr_rms(o.dW[l], od.dW[l]), relerr_rms(o.db[l], od.db[l])
+        rec[l] = {"dW_rms_vs_fp64acc_oracle": relerr_rms(dw[l], od.dW[l]), "oracle_fp32acc_vs_fp64acc_spread": spread_w,
+                  "db_rms": relerr_rms(dbb[l], od.db[l]), "W": relerr(w[l], o.W[l])}
+        parity_record(config="C5 one step, 512 frames, bf16", forward_vs_bf16_oracle=e_fwd, layers=rec, bar="2e-2 (+1.5x the oracle's own spread for the momentum state)")
         assert relerr_rms(dw[l], od.dW[l]) < TOL_BF16 + 1.5 * spread_w, ("dW", l, relerr_rms(dw[l], od.dW[l]), spread_w)
         assert relerr_rms(dbb[l], od.db[l]) < TOL_BF16 + 1.5 * spread_b, ("db", l, relerr_rms(dbb[l], od.db[l]), spread_b)
         assert relerr(w[l], o.W[l]) < TOL_BF16, ("W", l)
