@@ -483,7 +483,7 @@ def live_counters():
     """HBM-side traffic of the dominant launch and counter-based MFMA utilisation, measured in THIS run:
     three short rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES + SQ_BUSY_CU_CYCLES)."""
     is_wgrad = lambda k: k.startswith("void bp_wgrad_dma<16, 4, 4, 256, false>")          # noqa: E731
-    is_hidden = lambda k: k.startswith("void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>")   # noqa: E731  (TAG 0 = layers 2..L-2)
+    is_hidden = lambda k: k.startswith("void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 0>")   # noqa: E731  (EPI 0 = hidden forward, TAG 0 = layers 2..L-2)
     out = {}
     fe, wr = live_pmc(["FETCH_SIZE"]), live_pmc(["WRITE_SIZE"])
     kf, vf = _pick(fe, is_wgrad)

@@ -12,8 +12,8 @@
 // (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) is a conflict-free ds_read_b32 of 32
 // consecutive dwords per half-wave.  k-contiguous global operands are transposed on the way
 // in (float4 global load -> 4 x ds_write_b32, odd row stride => conflict-free); m/n-contiguous
-// operands go in with ds_write_b128.  Register-staged software pipeline: global loads of k-tiles
-// t+1..t+PF are in flight while tile t is multiplied; LDS double buffered, one barrier per k-tile.
+// operands go in with ds_write_b128.  Register-staged software pipeline: the global loads of k-tile
+// t+2 are in flight while tile t is multiplied and tile t+1 moves into the other LDS stage; one barrier per k-tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -149,33 +149,13 @@ __device__ __forceinline__ T *sgpr_row_base(T *p)
     return (T *)q;
 }
 
-// MFMA slot (0..NK-1 of a k-tile) after which piece q of the next tile's global loads / of the LDS stores of the
-// tile loaded one iteration earlier is issued.  Default: both spread evenly over the k-tile.
-#ifndef BP_LOAD_SLOT
-#define BP_LOAD_SLOT(q, NK, NP) (((q) * (NK)) / (NP))
-#endif
-#ifndef BP_STORE_SLOT
-#define BP_STORE_SLOT(q, NK, NP) (((q) * (NK)) / (NP))
-#endif
-
-#ifndef BP_WGRAD_NFAST
-#define BP_WGRAD_NFAST 1
-#endif
-
-// wgrad block orientation.  1: the natural MFMA layout (lane -> column n, registers -> rows): every
-// W / delta load and store is two full 128-byte rows.  0: transposed block (operands swapped in the
-// MFMA), lane -> row m and 4 registers -> 4 consecutive columns: float4 accesses, but each
-// instruction touches 32 rows x 32 bytes (quarter lines).
-#ifndef BP_WGRAD_LANE_N
-#define BP_WGRAD_LANE_N 1
-#endif
-
 // Registers [R0, R0+RN) of one 32x32 accumulator block (after an in-workgroup k-split every wave
 // finishes 16/KS of the block's registers).
 template <int EPI, int R0, int RN>
 __device__ __forceinline__ void epilogue_fetch(const EpiArgs &e, int mb, int nb, int lane, EpiPre &p)
 {
-    if constexpr (EPI == EPI_WGRAD_UPDATE && BP_WGRAD_LANE_N) {
+    if constexpr (EPI == EPI_WGRAD_UPDATE) {
+        // natural MFMA layout (lane -> column n, registers -> rows): every W / delta load and store is two full 128-byte rows
         // uniform row base (SGPRs) + one per-lane 32-bit offset: no per-row address VGPRs.  m_limit is a
         // multiple of 32 (padded widths), so a 32-row block is wholly inside or wholly outside the matrix;
         // outside blocks read row 0 and are never stored.
@@ -189,20 +169,6 @@ __device__ __forceinline__ void epilogue_fetch(const EpiArgs &e, int mb, int nb,
             const unsigned ro = (unsigned)((r & 3) + 8 * (r >> 2)) * ldc;
             p.p0[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sgpr_row_base(cw + ro)) + lob);
             p.p1[r] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(sgpr_row_base(cd + ro)) + lob);
-        }
-        return;
-    }
-    if constexpr (EPI == EPI_WGRAD_UPDATE) {
-        // transposed block (GemmCfg::SWAP): lane -> row m, registers 4q..4q+3 -> columns n0..n0+3
-        const int m = mb + (lane & 31);
-        const int mc = m < e.m_limit ? m : e.m_limit - 1;          // (rows past the matrix are never stored)
-#pragma unroll
-        for (int q = R0 / 4; q < (R0 + RN) / 4; ++q) {
-            const size_t idx = (size_t)mc * e.ldc + nb + 8 * q + 4 * (lane >> 5);
-            const float4 w = *reinterpret_cast<const float4 *>(e.C + idx);
-            const float4 d = *reinterpret_cast<const float4 *>(e.aux2 + idx);
-            p.p0[4 * q + 0] = w.x; p.p0[4 * q + 1] = w.y; p.p0[4 * q + 2] = w.z; p.p0[4 * q + 3] = w.w;
-            p.p1[4 * q + 0] = d.x; p.p1[4 * q + 1] = d.y; p.p1[4 * q + 2] = d.z; p.p1[4 * q + 3] = d.w;
         }
         return;
     }
@@ -225,7 +191,7 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
                                                const EpiPre &p)
 {
     static_assert(RN % 4 == 0 && R0 % 4 == 0, "register range must cover whole 4-row groups");
-    if constexpr ((EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) && BP_WGRAD_LANE_N) {
+    if constexpr (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) {
         const int n = nb + (lane & 31);
         if (n >= e.n_limit || mb >= e.m_limit) return;              // (m_limit % 32 == 0: whole block in or out)
         float *cw = uniform_ptr(e.C + (size_t)mb * e.ldc + nb);
@@ -245,31 +211,6 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
                 // vmcnt the tile is in memory whatever kind of allocation the gradient buffer is, which is what lets the tile count
                 // of bp_wgrad_dma.h hand the segment to the peers without a kernel boundary or an L2 write-back (bp_dp.h)
                 __hip_atomic_store(reinterpret_cast<float *>(reinterpret_cast<char *>(sgpr_row_base(cw + ro)) + lob), acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-        return;
-    }
-    if constexpr (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) {
-        // transposed block (GemmCfg::SWAP): lane -> row m, registers 4q..4q+3 -> columns n0..n0+3
-        const int m = mb + (lane & 31);
-        if (m >= e.m_limit) return;
-#pragma unroll
-        for (int q = R0 / 4; q < (R0 + RN) / 4; ++q) {
-            const int n0 = nb + 8 * q + 4 * (lane >> 5);
-            if (n0 >= e.n_limit) continue;
-            const size_t i = (size_t)m * e.ldc + n0;
-            if constexpr (EPI == EPI_WGRAD_UPDATE) {
-                float dv[4], wv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float w = p.p0[4 * q + j];
-                    const float d = e.mom * p.p1[4 * q + j] - e.c1 * (acc[4 * q + j] / e.ndiv + e.wc * w);   // kernUpdatedelta
-                    dv[j] = d; wv[j] = d + 1.0f * w;                                                         // kernAccSum
-                }
-                *reinterpret_cast<float4 *>(e.aux2 + i) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                *reinterpret_cast<float4 *>(e.C + i) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-            } else {
-                *reinterpret_cast<float4 *>(e.C + i) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
             }
         }
         return;
@@ -314,8 +255,6 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             if (m < e.m_limit) e.C[(size_t)m * e.ldc + n] = act_bwd(e.act, p.p0[r]) * acc[r];   // kernDsigmoid*kernVecMul
         }
-    } else if constexpr (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE) {
-        // handled above (transposed layout)
     } else {  // EPI_PARTIAL: plain store
 #pragma unroll
         for (int r = R0; r < R0 + RN; ++r) {
@@ -351,18 +290,6 @@ __device__ __forceinline__ void ksplit_take(f32x16 &acc, const float *red, int w
     }
 }
 
-// Pieces [LO, HI) of the epilogue-input fetch of a wave's TM x TN blocks; piece = (block i, j; 4-register
-// group q).  Lets the fully unrolled k-loop spread the fetch over its iterations.
-template <int EPI, int TM, int TN, int LO, int HI>
-__device__ __forceinline__ void epilogue_fetch_pieces(const EpiArgs &e, int mb0, int nb0, int lane, EpiPre (&pre)[TM][TN])
-{
-    if constexpr (LO < HI && LO < TM * TN * 4) {
-        constexpr int i = LO / (TN * 4), j = (LO / 4) % TN, q = LO % 4;
-        epilogue_fetch<EPI, 4 * q, 4>(e, mb0 + i * 32, nb0 + j * 32, lane, pre[i][j]);
-        epilogue_fetch_pieces<EPI, TM, TN, LO + 1, HI>(e, mb0, nb0, lane, pre);
-    }
-}
-
 // ------------------------------------------------------------------ the GEMM
 // Register image of one k-tile of both operands (global -> registers -> LDS staging).
 template <int NVA, int NVB>
@@ -371,8 +298,7 @@ struct TileRegs { float4 a[NVA]; float4 b[NVB]; };
 // BM x BN x BK workgroup tile, 4 waves arranged WM x WN x KS (KS = 4/(WM*WN) splits each
 // k-tile between wave groups; partial sums meet in LDS before the epilogue).
 // A_KC: A is [m][k] in memory (k contiguous) else [k][m]; B_KC: B is [n][k] else [k][n].
-// PF = k-tiles in flight in registers beyond the one being staged into LDS (1..2).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI>
 struct GemmCfg {
     static constexpr int KS = 4 / (WM * WN);
     static constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -382,15 +308,9 @@ struct GemmCfg {
     static constexpr int NVA = BM * BK / 4 / 256, NVB = BN * BK / 4 / 256;
     static constexpr int LPS = (BK / 4 < 8) ? BK / 4 : 8;     // lanes per 128-byte row segment
     static constexpr bool BIASG = (EPI == EPI_WGRAD_UPDATE || EPI == EPI_WGRAD_STORE);
-    // wgrad computes the TRANSPOSED 32x32 blocks (operands swapped in the MFMA): a lane then holds
-    // one row m of W/delta/G and, in registers 4q..4q+3, four CONSECUTIVE columns -- so the epilogue
-    // reads and writes W, delta, G as float4 (4x fewer memory instructions than one dword per
-    // register; the update's loads/stores are instruction-issue bound, not bandwidth bound).
-    static constexpr bool SWAP = BIASG && !BP_WGRAD_LANE_N;
     static_assert(WM * WN * KS == 4 && TM >= 1 && TN >= 1, "wave layout");
     static_assert(BK % (2 * KS) == 0 && BK % 4 == 0, "BK");
     static_assert(NVA >= 1 && NVB >= 1, "tile too small for 256 threads");
-    static_assert(PF >= 1 && PF <= 2, "PF (k-tiles in flight beyond the one being staged)");
     using Regs = TileRegs<NVA, NVB>;
 
     // Addressing: uniform tile base (SGPR) + per-thread 32-bit offset that never changes, so a
@@ -520,9 +440,7 @@ struct GemmCfg {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[s % NCH][i][j] = SWAP
-                        ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[s][j], av[s][i], acc[s % NCH][i][j], 0, 0, 0)
-                        : __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[s % NCH][i][j], 0, 0, 0);
+                    acc[s % NCH][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][i], bv[s][j], acc[s % NCH][i][j], 0, 0, 0);
             if (s + RD < NK) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[s + RD][i] = ap[2 * (s + RD) * LDA_S + i * 32];
@@ -531,8 +449,8 @@ struct GemmCfg {
             }
             if constexpr (DO_LOAD) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {               // load piece q goes after MFMA step q*NK/NP
-                    if (q == pl && BP_LOAD_SLOT(q, NK, NP) == s) {
+                for (int q = 0; q < NP; ++q) {               // load piece q goes after MFMA step q*NK/NP (spread evenly over the k-tile)
+                    if (q == pl && (q * NK) / NP == s) {
                         if (q < NVA) load_a(rl, q, pa, o); else load_b(rl, q - NVA, pb, o);
                         ++pl;
                     }
@@ -541,7 +459,7 @@ struct GemmCfg {
             if constexpr (DO_STORE) {
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {               // store piece q: same slots
-                    if (q == ps && BP_STORE_SLOT(q, NK, NP) == s) {
+                    if (q == ps && (q * NK) / NP == s) {
                         if (q < NVA) store_a(rs, q, AsN, tid); else store_b(rs, q - NVA, BsN, tid, bsum);
                         ++ps;
                     }
@@ -555,15 +473,9 @@ struct GemmCfg {
 // The workgroup program of one GEMM problem: workgroups first_block, first_block+stride, ... of
 // the launch walk its tiles.  Wrapped by bp_gemm (one problem per launch) and bp_gemm_dual (two
 // independent problems in one launch, see there).
-// NT_S > 0: the reduction is exactly NT_S k-tiles (host guarantees K == NT_S*BK) and the k-loop is
-// fully unrolled, which lets the W/delta fetch of the fused update be issued one piece per iteration
-// (static register indices).  Why: s_waitcnt vmcnt is in-order, so when all of it is issued up front
-// the very first operand-tile wait also waits for that whole burst (67 MB chip-wide for a 2048x2048
-// layer) -- the prologue of wgrad then takes 4.2 us instead of 1.3 us (in-kernel timestamps).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI>
 struct GemmKernel {
-    using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF>;
-    static constexpr bool STATIC_K = NT_S > 0 && PF == 1 && EPI == EPI_WGRAD_UPDATE && Cfg::KS == 1 && NT_S <= 32 && NT_S >= 4;
+    using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI>;
     static constexpr int KS = Cfg::KS, TM = Cfg::TM, TN = Cfg::TN;
     static constexpr int A_STAGE = Cfg::A_STAGE, B_STAGE = Cfg::B_STAGE, STAGE = A_STAGE + B_STAGE;
     static constexpr bool BIASG = Cfg::BIASG;
@@ -572,7 +484,7 @@ struct GemmKernel {
     static constexpr int SMEM0 = (2 * STAGE > RED) ? 2 * STAGE : RED;
     static constexpr int SMEM = SMEM0 > BIASRED ? SMEM0 : BIASRED;       // floats of LDS
     // workgroups per CU the register allocator must leave room for (launch bounds)
-    static constexpr int MIN_WG = (SMEM * 4 > 80 * 1024) ? 1 : (STATIC_K ? 3 : 2);
+    static constexpr int MIN_WG = (SMEM * 4 > 80 * 1024) ? 1 : 2;
 
 static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &e_in, int first_block, int stride,
                                            int block_y, float *smem)
@@ -595,8 +507,8 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     // one tile are still draining while the next tile's k-loop runs.
 #ifdef BP_TRACE
 #define TRACE(i) do { if (tid == 0 && g.trace) { g.trace[(size_t)first_block * 8 + (i)] = wall_clock64();                 \
-        if ((i) == 0 && NT_S == 0) g.trace[(size_t)first_block * 8 + 6] = clock64();   /* shader-clock counter: */              \
-        if ((i) == 3 && NT_S == 0) g.trace[(size_t)first_block * 8 + 7] = clock64();   /* effective MHz of the run */           \
+        if ((i) == 0) g.trace[(size_t)first_block * 8 + 6] = clock64();   /* shader-clock counter: */              \
+        if ((i) == 3) g.trace[(size_t)first_block * 8 + 7] = clock64();   /* effective MHz of the run */           \
     } } while (0)
 #else
 #define TRACE(i) ((void)0)
@@ -607,16 +519,13 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     {
         if ((g.tiles_n & 7) == 0) {
             const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3;
-#if BP_WGRAD_NFAST
             if constexpr (BIASG) {
                 // wgrad: the XCD's few n-panels (dEdX columns) stay hot anyway; walk the m-panels (activation
                 // columns) slowly so the `per` workgroups that share one run back to back and the panel is fetched
                 // into this L2 once, instead of being evicted by the W/delta stream before its next use
                 tile_n = xcd * per + j % per;
                 tile_m = j / per;
-            } else
-#endif
-            {
+            } else {
                 tile_n = xcd * per + j / g.tiles_m;
                 tile_m = j % g.tiles_m;
             }
@@ -649,9 +558,7 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     // hides under the k-loop (same lane->element map as the accumulator).
     EpiPre pre[TM][TN];
     const int mb0 = m0 + wm * TM * 32, nb0 = n0 + wn * TN * 32;
-    if constexpr (STATIC_K) {
-        // fetched piecewise inside the unrolled k-loop below
-    } else if constexpr (KS == 1) {
+    if constexpr (KS == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -666,8 +573,8 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
         }
     }
 
-    // ---- software pipeline: LDS holds tile t (double buffered), register sets hold tiles
-    // t+1 .. t+PF in flight.  One barrier per k-tile.  Every load in the steady-state loop is
+    // ---- software pipeline: LDS holds tile t (double buffered), two register images hold tiles
+    // t+1 (landed, being staged) and t+2 (in flight).  One barrier per k-tile.  Every load in the steady-state loop is
     // unconditional (past the end the tile index is clamped and the data ignored): a
     // conditional load turns into a phi + copy and hipcc then waits for it right away.
     const int last_k0 = (nt - 1) * BK;
@@ -682,83 +589,30 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
 #define STEP(ST, LD, buf, RS, RL, TL)                                                                      \
     Cfg::template step<ST, LD>(AS(buf), BS(buf), accs, ks, a_off, b_off, kh, RS, AS((buf) ^ 1), BS((buf) ^ 1),    \
                                RL, PA(TL), PB(TL), offs, tid, bsum)
-    Regs r0, r1, r2;
+    Regs r0, r1;
     Cfg::load(r0, PA(0), PB(0), offs);
     Cfg::store(r0, AS(0), BS(0), tid, bsum);
     Cfg::load(r1, PA(1), PB(1), offs);
-    if constexpr (PF >= 2) Cfg::load(r2, PA(2), PB(2), offs);
     __syncthreads();
     TRACE(1);
-    // Invariant at the top of iteration t: LDS stage t&1 holds tile t; tile t+1 (and t+2 when
-    // PF == 2) are in flight / landed in registers.  The iteration multiplies tile t and, between
-    // the MFMAs, issues the global loads of tile t+1+PF and moves tile t+1 into the other stage.
-    // The steady-state loops contain no conditionals (a conditional step makes hipcc copy the
-    // accumulators between register ranges every iteration); the last 1..PF+1 tiles run after.
+    // Invariant at the top of iteration t: LDS stage t&1 holds tile t; tile t+1 is in flight / landed in registers
+    // (r1 for even t, r0 for odd t).  The iteration multiplies tile t and, between the MFMAs, issues the global loads of tile
+    // t+2 and moves tile t+1 into the other stage.  The steady-state loop contains no conditionals (a conditional step makes
+    // hipcc copy the accumulators between register ranges every iteration); the last one or two tiles run after.
     int t = 0, buf = 0;
-    if constexpr (STATIC_K) {
-        // fully unrolled: iteration T multiplies tile T (stage T&1), stores tile T+1, loads tile T+2 and then
-        // issues its share of the W/delta pieces -- younger than this iteration's tile loads, so the
-        // in-order wait for the next tile does not include it and it has ~2 iterations to land
-        constexpr int NPRE = TM * TN * 4, PER = (NPRE + NT_S - 4) / (NT_S - 3);
-#define SBODY(T)                                                                                               \
-        if constexpr ((T) < NT_S) {                                                                            \
-            if constexpr ((T) % 2 == 0)                                                                        \
-                Cfg::template step<((T) + 1 < NT_S), ((T) + 2 < NT_S)>(AS(0), BS(0), accs, ks, a_off, b_off, kh, r1, AS(1), BS(1), \
-                                                                     r0, PA((T) + 2), PB((T) + 2), offs, tid, bsum);    \
-            else                                                                                               \
-                Cfg::template step<((T) + 1 < NT_S), ((T) + 2 < NT_S)>(AS(1), BS(1), accs, ks, a_off, b_off, kh, r0, AS(0), BS(0), \
-                                                                     r1, PA((T) + 2), PB((T) + 2), offs, tid, bsum);    \
-            __syncthreads();                                                                                   \
-            epilogue_fetch_pieces<EPI, TM, TN, (T) * PER, ((T) + 1) * PER>(e, mb0, nb0, lane, pre);            \
-            if constexpr ((T) < 4) TRACE(4 + (T));                                                             \
-        }
-        SBODY(0) SBODY(1) SBODY(2) SBODY(3) SBODY(4) SBODY(5) SBODY(6) SBODY(7)
-        SBODY(8) SBODY(9) SBODY(10) SBODY(11) SBODY(12) SBODY(13) SBODY(14) SBODY(15)
-        SBODY(16) SBODY(17) SBODY(18) SBODY(19) SBODY(20) SBODY(21) SBODY(22) SBODY(23)
-        SBODY(24) SBODY(25) SBODY(26) SBODY(27) SBODY(28) SBODY(29) SBODY(30) SBODY(31)
-#undef SBODY
-        epilogue_fetch_pieces<EPI, TM, TN, NT_S * PER, NPRE>(e, mb0, nb0, lane, pre);   // (none left when PER covers all)
-    } else
-    if constexpr (PF == 1) {
-        // tile t+1 in r1 (even t) / r0 (odd t)
-        for (; t + 3 <= nt; t += 2) {
-            STEP(true, true, 0, r1, r0, t + 2);
-            __syncthreads();
-            STEP(true, true, 1, r0, r1, t + 3);
-            __syncthreads();
-        }
-        if (nt - t == 2) {
-            STEP(true, false, 0, r1, r0, 0);
-            __syncthreads();
-            buf = 1;
-        }
-    } else {
-        // rotation r1 -> r2 -> r0: tile t+1 lives in r1, r2, r0 for t = 0, 1, 2 (mod 3)
-        for (; t + 4 <= nt; t += 3) {
-            buf = t & 1;
-            STEP(true, true, buf, r1, r0, t + 3);
-            __syncthreads();
-            STEP(true, true, buf ^ 1, r2, r1, t + 4);
-            __syncthreads();
-            STEP(true, true, buf, r0, r2, t + 5);
-            __syncthreads();
-        }
-        buf = t & 1;
-        if (nt - t >= 2) {
-            STEP(true, false, buf, r1, r0, 0);
-            __syncthreads();
-            buf ^= 1;
-            if (nt - t == 3) {
-                STEP(true, false, buf, r2, r0, 0);
-                __syncthreads();
-                buf ^= 1;
-            }
-        }
-    }
-    if constexpr (!STATIC_K) {
-        STEP(false, false, buf, r0, r0, 0);    // last tile: nothing left to stage or fetch
+    for (; t + 3 <= nt; t += 2) {
+        STEP(true, true, 0, r1, r0, t + 2);
+        __syncthreads();
+        STEP(true, true, 1, r0, r1, t + 3);
         __syncthreads();
     }
+    if (nt - t == 2) {
+        STEP(true, false, 0, r1, r0, 0);
+        __syncthreads();
+        buf = 1;
+    }
+    STEP(false, false, buf, r0, r0, 0);    // last tile: nothing left to stage or fetch
+    __syncthreads();
     TRACE(2);
 #undef K0_OF
 #undef PA
@@ -842,10 +696,10 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
 };   // GemmKernel
 
 // TAG only separates instantiations by name (profilers report per kernel name): 1 = input-layer forward.
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int NT_S = 0, int TAG = 0>
-__global__ __launch_bounds__(256, (GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>::MIN_WG)) void bp_gemm(const GemmArgs g, const EpiArgs e)
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int TAG = 0>
+__global__ __launch_bounds__(256, (GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI>::MIN_WG)) void bp_gemm(const GemmArgs g, const EpiArgs e)
 {
-    using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, NT_S>;
+    using K = GemmKernel<BM, BN, BK, WM, WN, A_KC, B_KC, EPI>;
     __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
     K::run(g, e, blockIdx.x, gridDim.x, blockIdx.y, smem);
 }

@@ -241,14 +241,14 @@ extern "C" int bp_sync(bp_handle *h)
 }
 
 // ------------------------------------------------------------------ launches
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int PF = 1, int TAG = 0>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int TAG = 0>
 static hipError_t launch(hipStream_t st, GemmArgs g, const EpiArgs &e, int M, int N, int max_grid = 0)
 {
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     int grid = g.tiles_m * g.tiles_n;
     if (max_grid > 0 && grid > max_grid) grid = max_grid;     // persistent: workgroups loop over tiles
-    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, PF, 0, TAG>), dim3(grid), dim3(256), 0, st, g, e);
+    hipLaunchKernelGGL((bp_gemm<BM, BN, BK, WM, WN, A_KC, B_KC, EPI, TAG>), dim3(grid), dim3(256), 0, st, g, e);
     return hipGetLastError();
 }
 
@@ -277,7 +277,7 @@ hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y
         e.step = h->step; e.layer = (uint32_t)l; e.frame_off = h->cfg.rank_frame_offset;
         if (train && h->inj_mask[l]) { e.mask = h->inj_mask[l]; e.ldmask = h->s[l]; e.drop_thresh = 1u; }   // injected mask (tests)
         if (cur <= 512) return launch<32, 32, 64, 1, 1, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
-        if (l == 1) return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1, 1>(st, g, e, M, cur);   // (own name in profiles)
+        if (l == 1) return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>(st, g, e, M, cur);   // (TAG 1: own name in profiles)
         return launch<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>(st, g, e, M, cur);
     }
     e.scale = 2.0f / (float)h->Bg;                       // kernSubClean: 2.0f/rows (global rows under DP)
@@ -285,7 +285,7 @@ hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y
         g.K = prev / h->out_splits; g.k_split = g.K; g.slab_stride = h->slab_stride;
         e.C = h->slabs; e.ldc = cur;
         g.tiles_m = (M + 31) / 32; g.tiles_n = (cur + 31) / 32;
-        hipLaunchKernelGGL((bp_gemm<32, 32, 64, 1, 1, true, false, EPI_PARTIAL, 1>),
+        hipLaunchKernelGGL((bp_gemm<32, 32, 64, 1, 1, true, false, EPI_PARTIAL>),
                            dim3(g.tiles_m * g.tiles_n, h->out_splits), dim3(256), 0, st, g, e);
         hipError_t er = hipGetLastError();
         if (er != hipSuccess) return er;
@@ -325,7 +325,7 @@ using KDgradNarrow = GemmKernel<32, 32, 64, 1, 1, true, true, EPI_DGRAD>;
 // (128x64 tiles move 25 % less through L2 but fit only 2 per CU: 0.242 vs 0.230 ms per C2 step).
 template <int EPI> using KWgrad = GemmKernel<64, 64, 32, 2, 2, false, false, EPI>;
 // bunch of 256 frames (the benchmark configuration): LDS-DMA staged, fully unrolled kernel of bp_wgrad_dma.h; the
-// register-staged unrolled form it replaced was GemmKernel<64, 64, 32, 2, 2, false, false, EPI_WGRAD_UPDATE, 1, 8> (84.7 vs 80.4 us)
+// register-staged, fully unrolled form it replaced (84.7 vs 80.4 us) left the tree in round 6 (git ed4dac3 has it)
 // data-parallel gradient store (no W/delta to carry): 128x64x16 tiles are 136 VGPRs and measured faster there
 using KWgradStore = GemmKernel<128, 64, 16, 2, 2, false, false, EPI_WGRAD_STORE>;
 

@@ -158,7 +158,7 @@ with open(os.path.join(d, "host", "1", "p_counter_collection.csv"), "w") as f:
     for c in counters:
         for v in vals[c]:
             f.write('"void bp_wgrad_dma<16, 4, 4, 256, false>(MultiArgs)",933888,%s,%r\\n' % (c, v))
-            f.write('"void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>(GemmArgs, EpiArgs)",65536,%s,%r\\n' % (c, v / 4))
+            f.write('"void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 0>(GemmArgs, EpiArgs)",65536,%s,%r\\n' % (c, v / 4))
 """)
     fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
     monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
