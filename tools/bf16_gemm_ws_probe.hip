@@ -44,8 +44,10 @@ __global__ void ref_gemm(const bf16_t *A, const bf16_t *B, float *C, int M, int 
 }
 
 // ------------------------------------------------------------------ baseline: the loop of rounds 4-5 (4 waves, everybody does everything)
-template <int ST, bool BKN, int RA>
-__global__ __launch_bounds__(256) void gemm_dma_v2(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n, int stag)
+__device__ __forceinline__ void pf_wave(const bf16_t *B, int ldb, int n0, int nt, int tile_m, int tiles_m, int lane, bool bkn, int pfd);
+// PFD > 0: a FIFTH wave that only prefetches (pf_wave, below) and joins the per-tile barrier
+template <int ST, bool BKN, int RA, int PFD = 0>
+__global__ __launch_bounds__(PFD ? 320 : 256) void gemm_dma_v2(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n, int stag)
 {
     constexpr int STAGE = 192 * 128, D = ST - 1;
     constexpr int NRD = BKN ? 4 : 3;
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(256) void gemm_dma_v2(const bf16_t *A, const bf16_t
     int tile_m, tile_n;
     { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
     const int m0 = tile_m * 128, n0 = tile_n * 64;
+    if (PFD && wave == 4) { pf_wave(B, ldb, n0, K / 64, tile_m, tiles_m, lane, BKN, PFD); return; }   // (not with krep)
     const bf16_t *src[6]; size_t step[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -61,11 +64,12 @@ __global__ __launch_bounds__(256) void gemm_dma_v2(const bf16_t *A, const bf16_t
         if (r < 128 || !BKN) { const int c = (lane & 7) ^ ((r >> 1) & 7); src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + c * 8; step[i] = 64; }
         else { const int k = r - 128, c = (lane & 7) ^ (4 * ((k >> 1) & 1)); src[i] = B + (size_t)k * ldb + n0 + c * 8; step[i] = (size_t)64 * ldb; }
     }
-    const int nt = K / 64;
-    const int rot = (tile_m * stag) % nt;
+    const int krep = stag >= 1000 ? stag / 1000 : 1; stag %= 1000;
+    const int ntr = K / 64, nt = ntr * krep;
+    const int rot = (tile_m * stag) % ntr;
     auto issue_piece = [&](int i, int t, int st) {
-        int tt = t < nt ? t : nt - 1;
-        tt += rot; if (tt >= nt) tt -= nt;
+        int tt = (t < nt ? t : nt - 1) % ntr;
+        tt += rot; if (tt >= ntr) tt -= ntr;
         __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * step[i]), (lds_ptr)(smem + st * STAGE + (wave * 6 + i) * 1024), 16, 0, 0);
     };
     const int ra = wm * 64 + (lane & 31), rb = 128 + wn * 32 + (lane & 31), h = lane >> 5;
@@ -146,8 +150,31 @@ __global__ __launch_bounds__(256) void gemm_dma_v2(const bf16_t *A, const bf16_t
 //                           tile t+1 at q = 2, 3) are issued behind the MFMAs of step g.  RA = 2 fragment sets in flight.
 // ABL: 0 = full kernel | 1 = producers issue no DMA in the loop (wrong result) | 2 = consumers read no fragments (wrong result)
 // PRIO: s_setprio value of the consumer waves (0 = leave alone)
-template <int ST, bool BKN, int NPW, int PRIO, int ABL = 0>
-__global__ __launch_bounds__(256 + 64 * NPW, 1) void gemm_ws(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n, int stag)
+// PFD > 0: one more wave, the PREFETCHER: behind barrier #t it touches the 64 lines of B's k-tile t+PFD (one 4-byte load per lane and
+// 128-byte line, result never used; its own vmcnt) if that tile is this m-tile's turn (t+PFD mod tiles_m): the m-tiles that share a
+// B panel sit on one XCD, so each line is pulled into that L2 ONCE, PFD tiles before the ring's DMA asks for it.  Why: the ring
+// keeps 3 tiles = 24 KB of B per CU in flight and the sharers of a panel ask for the SAME lines, i.e. 1.5 MB of unique weight bytes
+// in flight chip-wide -- at ~1 us of HBM latency that is the 1.2-1.5 TB/s the cold launches measure.
+__device__ __forceinline__ void pf_wave(const bf16_t *B, int ldb, int n0, int nt, int tile_m, int tiles_m, int lane, bool bkn, int pfd)
+{
+    const bf16_t *line = bkn ? B + (size_t)lane * ldb + n0 : B + (size_t)(n0 + lane) * ldb;    // line `lane` of k-tile 0
+    const size_t step = bkn ? (size_t)64 * ldb : 64;
+    // The load's destination register is written when the data RETURNS: it must stay allocated to `junk` until the final wait
+    // ("+v" chains every touch through the same register; a plain "=v" output is dead at once and the register gets reused).
+    unsigned junk = 0;
+    auto touch = [&](int t) {
+        if (t < nt && t % tiles_m == tile_m)
+            asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(line + (size_t)t * step) : "memory");
+    };
+    for (int t = 3; t < pfd; ++t) touch(t);                     // (tiles 0..2 are the producers' prologue)
+    for (int t = 0; t < nt; ++t) {
+        __builtin_amdgcn_s_barrier();
+        touch(t + pfd);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(junk) :: "memory");
+}
+template <int ST, bool BKN, int NPW, int PRIO, int ABL = 0, int PFD = 0>
+__global__ __launch_bounds__(256 + 64 * NPW + (PFD ? 64 : 0), 1) void gemm_ws(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n, int stag)
 {
     static_assert(24 % NPW == 0 && ST >= 4, "producer waves must divide the 24 pieces of a k-tile; ring of at least 4");
     constexpr int STAGE = 192 * 128, PP = 24 / NPW;
@@ -158,6 +185,7 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void gemm_ws(const bf16_t *A, co
     { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
     const int m0 = tile_m * 128, n0 = tile_n * 64;
     const int nt = K / 64;
+    if (PFD && wave == 4 + NPW) { pf_wave(B, ldb, n0, nt, tile_m, tiles_m, lane, BKN, PFD); return; }
     if (wave >= 4) {
         // ---------------- producer
         const int pw = wave - 4;
@@ -255,6 +283,241 @@ __global__ __launch_bounds__(256 + 64 * NPW, 1) void gemm_ws(const bf16_t *A, co
         }
 }
 
+// ------------------------------------------------------------------ wave-specialised, consumers split k INSIDE the k-tile
+// Consumer wave w takes k-step w (16 of the tile's 64 k) for the WHOLE 128 x 64 tile: 8 accumulator blocks (128 registers), per k-tile
+// 4 A fragments + 2 B fragments for 8 MFMAs -- half the fragment bytes out of LDS that the 2 x 2 arrangement reads (each fragment
+// feeds 2 resp. 4 MFMAs instead of 1 resp. 2), eight independent accumulator chains.  The four partial tiles meet once, after
+// the k-loop, through the (then free) ring: wave w hands the six blocks it does not own to their owners and finishes blocks
+// 2w, 2w+1 -- every wave runs a quarter of the epilogue.  Fragment registers are double buffered by name: the reads of tile t+1
+// (certified by barrier #t) are issued before the MFMAs of tile t.
+template <int ST, bool BKN, int NPW, int PFD = 0, int ABL = 0>
+__global__ __launch_bounds__(256 + 64 * NPW, 1) void gemm_ws2(const bf16_t *A, const bf16_t *B, float *C, int lda, int ldb, int ldc, int K, int tiles_m, int tiles_n, int stag)
+{
+    static_assert(24 % NPW == 0 && ST >= 4, "producer waves must divide the 24 pieces of a k-tile; ring of at least 4");
+    constexpr int STAGE = 192 * 128, PP = 24 / NPW;
+    __shared__ __attribute__((aligned(1024))) char smem[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n;
+    { const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = tiles_n >> 3; tile_n = xcd * per + jj / tiles_m; tile_m = jj % tiles_m; }
+    const int m0 = tile_m * 128, n0 = tile_n * 64;
+    // timing aid: stag = 1000*krep + stag walks the k range krep times (wrong result; slope per k-tile = (T(2) - T(1)) / (K/64))
+    const int krep = stag >= 1000 ? stag / 1000 : 1; stag %= 1000;
+    const int ntr = K / 64, nt = ntr * krep;
+    if (wave >= 4) {
+        const int pw = wave - 4;
+        const bf16_t *src[PP]; size_t step[PP];
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+            const int r = 8 * (pw * PP + i) + (lane >> 3);
+            if (r < 128 || !BKN) { const int c = (lane & 7) ^ ((r >> 1) & 7); src[i] = (r < 128 ? A + (size_t)(m0 + r) * lda : B + (size_t)(n0 + r - 128) * ldb) + c * 8; step[i] = 64; }
+            else { const int k = r - 128, c = (lane & 7) ^ (4 * ((k >> 1) & 1)); src[i] = B + (size_t)k * ldb + n0 + c * 8; step[i] = (size_t)64 * ldb; }
+        }
+        const int rot = (tile_m * stag) % ntr;
+        auto issue_tile = [&](int t, int st) {
+            int tt = (t < nt ? t : nt - 1) % ntr;
+            tt += rot; if (tt >= ntr) tt -= ntr;
+#pragma unroll
+            for (int i = 0; i < PP; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(src[i] + (size_t)tt * step[i]), (lds_ptr)(smem + st * STAGE + (pw * PP + i) * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int t = 0; t < ST - 1; ++t) issue_tile(t, t);
+        int stn = ST - 1;
+        for (int t = 0; t < nt; ++t) {
+            VmWait<(ST - 3) * PP>::go();
+            if (ABL != 3 && ABL != 5) __builtin_amdgcn_s_barrier();
+            if (ABL == 0 || ABL == 2 || ABL == 6) issue_tile(t + ST - 1, stn);
+            stn = stn + 1 == ST ? 0 : stn + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // ---------------- consumer `wave`: k-step `wave` of every k-tile
+    const int h = lane >> 5, rl = lane & 31, sa = (rl >> 1) & 7;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)smem;
+    // A fragment of block i (rows 32 i + rl): + 4096 i bytes.  Chunk 2 wave + h of the row, in slot chunk ^ sa (source swizzle of the DMA).
+    const unsigned aqa = lds0 + rl * 128 + 16 * (((2 * wave + h) ^ sa) & 7);
+    unsigned bqa[2];
+    if constexpr (BKN) {
+        const int j4 = (lane & 15) >> 2;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const int cb = 4 * jb + 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+            bqa[jb] = lds0 + 128 * 128 + (16 * wave + 8 * h + j4) * 128 + 16 * (cb ^ (4 * ((j4 >> 1) & 1))) + 8 * (lane & 1);
+        }
+    } else {
+        bqa[0] = lds0 + (128 + rl) * 128 + 16 * (((2 * wave + h) ^ sa) & 7);     // rows 128 + 32 jb + rl: the same swizzle (32 jb >> 1 is a multiple of 8)
+        bqa[1] = bqa[0] + 4096;
+    }
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jb][r] = 0.f;
+    struct Frag { f32x4v a[4]; f32x4v b[2]; v4s blo[2], bhi[2]; };
+    Frag f0, f1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f0.a[i] = 0.f; f1.a[i] = 0.f; }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) { f0.b[jb] = 0.f; f1.b[jb] = 0.f; f0.blo[jb] = 0; f0.bhi[jb] = 0; f1.blo[jb] = 0; f1.bhi[jb] = 0; }
+    constexpr int NRD = BKN ? 8 : 6;
+#define WS2_READS(F, so)                                                                                             \
+    do { if (ABL != 2 && ABL != 3 && ABL != 4) {                                                                     \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(F.a[0]) : "v"(aqa + (so)));                                        \
+        if constexpr (BKN) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(F.blo[0]) : "v"(bqa[0] + (so)));        \
+                             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(F.bhi[0]) : "v"(bqa[0] + (so))); } \
+        else asm volatile("ds_read_b128 %0, %1" : "=v"(F.b[0]) : "v"(bqa[0] + (so)));                                \
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=v"(F.a[1]) : "v"(aqa + (so)));                            \
+        if constexpr (BKN) { asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(F.blo[1]) : "v"(bqa[1] + (so)));        \
+                             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(F.bhi[1]) : "v"(bqa[1] + (so))); } \
+        else asm volatile("ds_read_b128 %0, %1" : "=v"(F.b[1]) : "v"(bqa[1] + (so)));                                \
+        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(F.a[2]) : "v"(aqa + (so)));                            \
+        asm volatile("ds_read_b128 %0, %1 offset:12288" : "=v"(F.a[3]) : "v"(aqa + (so)));                           \
+    } } while (0)
+// wait until at most N LDS reads are outstanding; everything of F issued before them has then arrived
+#define WS2_ARRIVED(F, N)                                                                                            \
+    do { if (ABL != 2 && ABL != 3 && ABL != 4) { if constexpr (BKN) asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]), "+v"(F.blo[0]), "+v"(F.bhi[0]), "+v"(F.blo[1]), "+v"(F.bhi[1]) : "n"(N)); \
+                         else asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(F.a[0]), "+v"(F.a[1]), "+v"(F.a[2]), "+v"(F.a[3]), "+v"(F.b[0]), "+v"(F.b[1]) : "n"(N)); } } while (0)
+#define WS2_MFMAS(F)                                                                                                 \
+    do { bf16x8_t b0_, b1_;                                                                                          \
+         if constexpr (BKN) { b0_ = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(F.blo[0], F.bhi[0], 0, 1, 2, 3, 4, 5, 6, 7)); \
+                              b1_ = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(F.blo[1], F.bhi[1], 0, 1, 2, 3, 4, 5, 6, 7)); } \
+         else { b0_ = __builtin_bit_cast(bf16x8_t, F.b[0]); b1_ = __builtin_bit_cast(bf16x8_t, F.b[1]); }            \
+         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                          \
+             acc[i_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, F.a[i_]), b0_, acc[i_][0], 0, 0, 0); \
+             acc[i_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, F.a[i_]), b1_, acc[i_][1], 0, 0, 0); } } while (0)
+    // PFD: consumer wave 0 is also the prefetcher (pf_wave above, folded in: the consumers never wait on vmcnt, so these loads cost
+    // one issue slot every tiles_m-th tile and nothing else; a ninth wave would put three waves on one SIMD = 168 registers)
+    const bf16_t *pf_line = BKN ? B + (size_t)lane * ldb + n0 : B + (size_t)(n0 + lane) * ldb;
+    const size_t pf_step = BKN ? (size_t)64 * ldb : 64;
+    unsigned junk = 0;                                          // (kept live until the final vmcnt(0): see pf_wave)
+    auto touch = [&](int t) {
+        if (PFD && wave == 0 && t < nt && t % tiles_m == tile_m)
+            asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(pf_line + (size_t)t * pf_step) : "memory");
+    };
+    for (int t = 3; t < PFD; ++t) touch(t);
+// ABL 6 / 7 (full kernel / no DMA): the reads of the NEXT tile one by one behind the MFMAs of this one (a ds_read issued in the shadow
+// of a 32-cycle MFMA costs nothing; six of them in a row idle the matrix pipe: +53 ns per k-tile, slope measurement of this probe)
+#define WS2_RD1(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define WS2_TR1(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define WS2_TILE_IL(FC, FN, son)                                                                                     \
+    do { WS2_ARRIVED(FC, 0);                                                                                         \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         bf16x8_t b0_, b1_;                                                                                          \
+         if constexpr (BKN) { b0_ = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(FC.blo[0], FC.bhi[0], 0, 1, 2, 3, 4, 5, 6, 7)); \
+                              b1_ = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(FC.blo[1], FC.bhi[1], 0, 1, 2, 3, 4, 5, 6, 7)); } \
+         else { b0_ = __builtin_bit_cast(bf16x8_t, FC.b[0]); b1_ = __builtin_bit_cast(bf16x8_t, FC.b[1]); }          \
+         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[0]), b0_, acc[0][0], 0, 0, 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         WS2_RD1(FN.a[0], aqa + (son), 0);                                                                           \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[0]), b1_, acc[0][1], 0, 0, 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         if constexpr (BKN) { WS2_TR1(FN.blo[0], bqa[0] + (son), 0); WS2_TR1(FN.bhi[0], bqa[0] + (son), 512); } else WS2_RD1(FN.b[0], bqa[0] + (son), 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[1]), b0_, acc[1][0], 0, 0, 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         WS2_RD1(FN.a[1], aqa + (son), 4096);                                                                        \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[1]), b1_, acc[1][1], 0, 0, 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         if constexpr (BKN) { WS2_TR1(FN.blo[1], bqa[1] + (son), 0); WS2_TR1(FN.bhi[1], bqa[1] + (son), 512); } else WS2_RD1(FN.b[1], bqa[1] + (son), 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[2]), b0_, acc[2][0], 0, 0, 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         WS2_RD1(FN.a[2], aqa + (son), 8192);                                                                        \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[2]), b1_, acc[2][1], 0, 0, 0); \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         WS2_RD1(FN.a[3], aqa + (son), 12288);                                                                       \
+         __builtin_amdgcn_sched_barrier(0);                                                                          \
+         acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[3]), b0_, acc[3][0], 0, 0, 0); \
+         acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, FC.a[3]), b1_, acc[3][1], 0, 0, 0); \
+         __builtin_amdgcn_sched_barrier(0); } while (0)
+    __builtin_amdgcn_s_barrier();                               // #0: tiles 0 and 1 have landed
+    __builtin_amdgcn_sched_barrier(0);
+    WS2_READS(f0, 0u);
+    unsigned so = 0u;
+    if constexpr (ABL == 6 || ABL == 7) {
+        for (int t = 0; t < nt; t += 2) {
+            const unsigned s1 = so + STAGE == ST * STAGE ? 0u : so + STAGE, s2 = s1 + STAGE == ST * STAGE ? 0u : s1 + STAGE;
+            touch(t + PFD);
+            WS2_TILE_IL(f0, f1, s1);                            // tile t; fetches the fragments of tile t+1 (certified by barrier #t)
+            __builtin_amdgcn_s_barrier();                       // #(t+1)
+            __builtin_amdgcn_sched_barrier(0);
+            touch(t + 1 + PFD);
+            WS2_TILE_IL(f1, f0, s2);
+            if (t + 2 < nt) __builtin_amdgcn_s_barrier();       // #(t+2)
+            __builtin_amdgcn_sched_barrier(0);
+            so = s2;
+        }
+    } else
+    // two tiles per trip (fragment sets by name); nt is even (K a multiple of 128)
+    for (int t = 0; t < nt; t += 2) {
+        const unsigned s1 = so + STAGE == ST * STAGE ? 0u : so + STAGE, s2 = s1 + STAGE == ST * STAGE ? 0u : s1 + STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        WS2_READS(f1, s1);                                      // tile t+1: certified by barrier #t
+        touch(t + PFD);
+        WS2_ARRIVED(f0, NRD);
+        __builtin_amdgcn_sched_barrier(0);
+        WS2_MFMAS(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 3 && ABL != 5) __builtin_amdgcn_s_barrier();   // #(t+1)
+        __builtin_amdgcn_sched_barrier(0);
+        WS2_READS(f0, s2);                                      // tile t+2 (behind the last tile: a stage that exists, contents unused)
+        touch(t + 1 + PFD);
+        WS2_ARRIVED(f1, NRD);
+        __builtin_amdgcn_sched_barrier(0);
+        WS2_MFMAS(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt && ABL != 3 && ABL != 5) __builtin_amdgcn_s_barrier();           // #(t+2)
+        so = s2;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (PFD) asm volatile("s_waitcnt vmcnt(0)" : "+v"(junk) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the four partial tiles meet: block b = 2 i + jb is finished by wave b >> 1.  Exchange area (the ring; the producers are
+    // done: their last pieces are duplicates nobody reads, and they drained vmcnt before leaving): [owner][giver slot 0..2][2 blocks][16 regs][64 lanes]
+    __builtin_amdgcn_s_barrier();                               // every consumer is past its last fragment read
+    float *xa = reinterpret_cast<float *>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i == wave) continue;
+        const int slot = wave < i ? wave : wave - 1;            // this giver's slot at owner i
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4v v; v[0] = acc[i][jb][4 * r4]; v[1] = acc[i][jb][4 * r4 + 1]; v[2] = acc[i][jb][4 * r4 + 2]; v[3] = acc[i][jb][4 * r4 + 3];
+                *reinterpret_cast<f32x4v *>(xa + ((((i * 3 + slot) * 2 + jb) * 4 + r4) * 64 + lane) * 4) = v;
+            }
+    }
+    __syncthreads();
+    // (acc[wave][.] indexed by a wave-uniform RUNTIME value would go through scratch: select by name)
+#define WS2_FINISH(W)                                                                                                \
+    if (wave == (W)) {                                                                                               \
+        _Pragma("unroll") for (int jb = 0; jb < 2; ++jb) {                                                           \
+            _Pragma("unroll") for (int sl = 0; sl < 3; ++sl)                                                         \
+                _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) {                                                   \
+                    const f32x4v v = *reinterpret_cast<const f32x4v *>(xa + (((((W) * 3 + sl) * 2 + jb) * 4 + r4) * 64 + lane) * 4); \
+                    acc[(W)][jb][4 * r4] += v[0]; acc[(W)][jb][4 * r4 + 1] += v[1]; acc[(W)][jb][4 * r4 + 2] += v[2]; acc[(W)][jb][4 * r4 + 3] += v[3]; \
+                }                                                                                                    \
+            const int n = n0 + jb * 32 + (lane & 31);                                                                \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                         \
+                const int m = m0 + (W) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);                              \
+                C[(size_t)m * ldc + n] = acc[(W)][jb][r];                                                            \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+    WS2_FINISH(0) WS2_FINISH(1) WS2_FINISH(2) WS2_FINISH(3)
+#undef WS2_FINISH
+#undef WS2_READS
+#undef WS2_ARRIVED
+#undef WS2_MFMAS
+}
+
 int main()
 {
     const int M = 512, N = 4096, K = 4096;
@@ -301,6 +564,88 @@ int main()
         fflush(stdout);
     };
 #define WS(ST, BKN, NPW, PRIO, ABL, Bp, ldb_, stag) hipLaunchKernelGGL((gemm_ws<ST, BKN, NPW, PRIO, ABL>), dim3(tm * tn), dim3(256 + 64 * NPW), 0, st, A, Bp, C, K, ldb_, N, K, tm, tn, stag)
+#define WS2(ST, BKN, NPW, PFD, ABL, Bp, ldb_, stag) hipLaunchKernelGGL((gemm_ws2<ST, BKN, NPW, PFD, ABL>), dim3(tm * tn), dim3(256 + 64 * NPW), 0, st, A, Bp, C, K, ldb_, N, K, tm, tn, stag)
+#define WSP(ST, BKN, NPW, PFD, Bp, ldb_, stag) hipLaunchKernelGGL((gemm_ws<ST, BKN, NPW, 0, 0, PFD>), dim3(tm * tn), dim3(256 + 64 * NPW + (PFD ? 64 : 0)), 0, st, A, Bp, C, K, ldb_, N, K, tm, tn, stag)
+    for (int pass = 0; pass < 2; ++pass) {
+        printf("---- pass %d: correctness + absolute times of the interleaved form\n", pass);
+        run("v2 (rounds 4-5) [n][k] warm", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, 0); });
+        run("v2 (rounds 4-5) [k][n] warm", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn, 0); });
+        run("ws2 interleaved [n][k] warm", [&] { WS2(5, false, 4, 0, 6, B, K, 0); });
+        run("ws2 interleaved [k][n] warm", [&] { WS2(5, true, 4, 0, 6, Bt, N, 0); });
+        run("ws2 interleaved, prefetch 16 [n][k] warm", [&] { WS2(5, false, 4, 16, 6, B, K, 0); });
+        run("v2 (rounds 4-5) [n][k] COLD, sharers 2 tiles apart", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 2); });
+        run("v2 (rounds 4-5) [k][n] COLD, sharers 4 tiles apart", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn, 4); });
+        run("v2 + prefetch wave 16 [n][k] COLD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2, 16>), dim3(tm * tn), dim3(320), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 0); });
+        run("ws2 interleaved, no prefetch [n][k] COLD", [&] { WS2(5, false, 4, 0, 6, Bs[rr++ & 7], K, 0); });
+        run("ws2 interleaved, prefetch 8 [n][k] COLD", [&] { WS2(5, false, 4, 8, 6, Bs[rr++ & 7], K, 0); });
+        run("ws2 interleaved, prefetch 16 [n][k] COLD", [&] { WS2(5, false, 4, 16, 6, Bs[rr++ & 7], K, 0); });
+        run("ws2 interleaved, prefetch 16 [k][n] COLD", [&] { WS2(5, true, 4, 16, 6, Bts[rr++ & 7], N, 0); });
+        run("ws2 interleaved, no prefetch [k][n] COLD", [&] { WS2(5, true, 4, 0, 6, Bts[rr++ & 7], N, 0); });
+    }
+    if (getenv("WS_ROUND2"))
+    for (int pass = 0; pass < 2; ++pass) {
+        printf("---- pass %d (round 2 of the probe: prefetch wave, k-split consumers)\n", pass);
+        run("v2 (rounds 4-5) [n][k] warm", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, 0); });
+        run("v2 (rounds 4-5) [k][n] warm", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bt, C, K, N, N, K, tm, tn, 0); });
+        run("ws2 (k-split consumers) ring 5, 4 producers [n][k] warm", [&] { WS2(5, false, 4, 0, 0, B, K, 0); });
+        run("ws2 ring 6, 4 producers [n][k] warm", [&] { WS2(6, false, 4, 0, 0, B, K, 0); });
+        run("ws2 ring 5, 4 producers [k][n] warm", [&] { WS2(5, true, 4, 0, 0, Bt, N, 0); });
+        run("  ws2 ring 5, 4 producers: no DMA in the loop (wrong result)", [&] { WS2(5, false, 4, 0, 1, B, K, 0); });
+        run("  ws2 ring 5, 4 producers: no fragment reads (wrong result)", [&] { WS2(5, false, 4, 0, 2, B, K, 0); });
+        run("ws2 ring 5, 4 producers, prefetch 16 [n][k] warm", [&] { WS2(5, false, 4, 16, 0, B, K, 0); });
+        run("v2 (rounds 4-5) [n][k] COLD, sharers 2 tiles apart", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 2); });
+        run("v2 (rounds 4-5) [k][n] COLD, sharers 4 tiles apart", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2>), dim3(tm * tn), dim3(256), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn, 4); });
+        run("v2 + prefetch wave 8 [n][k] COLD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2, 8>), dim3(tm * tn), dim3(320), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 0); });
+        run("v2 + prefetch wave 16 [n][k] COLD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2, 16>), dim3(tm * tn), dim3(320), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 0); });
+        run("v2 + prefetch wave 24 [n][k] COLD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2, 24>), dim3(tm * tn), dim3(320), 0, st, A, Bs[rr++ & 7], C, K, K, N, K, tm, tn, 0); });
+        run("v2 + prefetch wave 16 [k][n] COLD", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, true, 2, 16>), dim3(tm * tn), dim3(320), 0, st, A, Bts[rr++ & 7], C, K, N, N, K, tm, tn, 0); });
+        run("v2 + prefetch wave 16 [n][k] warm", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2, 16>), dim3(tm * tn), dim3(320), 0, st, A, B, C, K, K, N, K, tm, tn, 0); });
+        run("ws ring 5, 4 producers, no prefetch [n][k] COLD", [&] { WSP(5, false, 4, 0, Bs[rr++ & 7], K, 0); });
+        run("ws ring 5, 4 producers, prefetch 8 [n][k] COLD", [&] { WSP(5, false, 4, 8, Bs[rr++ & 7], K, 0); });
+        run("ws ring 5, 4 producers, prefetch 16 [n][k] COLD", [&] { WSP(5, false, 4, 16, Bs[rr++ & 7], K, 0); });
+        run("ws ring 5, 4 producers, prefetch 24 [n][k] COLD", [&] { WSP(5, false, 4, 24, Bs[rr++ & 7], K, 0); });
+        run("ws ring 5, 4 producers, prefetch 16 [k][n] COLD", [&] { WSP(5, true, 4, 16, Bts[rr++ & 7], N, 0); });
+        run("ws2 ring 5, 4 producers, no prefetch [n][k] COLD", [&] { WS2(5, false, 4, 0, 0, Bs[rr++ & 7], K, 0); });
+        run("ws2 ring 5, 4 producers, prefetch 8 [n][k] COLD", [&] { WS2(5, false, 4, 8, 0, Bs[rr++ & 7], K, 0); });
+        run("ws2 ring 5, 4 producers, prefetch 16 [n][k] COLD", [&] { WS2(5, false, 4, 16, 0, Bs[rr++ & 7], K, 0); });
+        run("ws2 ring 5, 4 producers, prefetch 24 [n][k] COLD", [&] { WS2(5, false, 4, 24, 0, Bs[rr++ & 7], K, 0); });
+        run("ws2 ring 5, 4 producers, prefetch 16 [k][n] COLD", [&] { WS2(5, true, 4, 16, 0, Bts[rr++ & 7], N, 0); });
+    }
+    {
+        printf("---- per-k-tile slopes: T(k range walked twice) - T(once), / 64 tiles; warm\n");
+        auto timeit = [&](auto launch) {
+            std::vector<float> ts;
+            for (int r = 0; r < 7; ++r) {
+                launch(); launch();
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < 20; ++i) launch();
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / 20 * 1000.f);
+            }
+            std::sort(ts.begin(), ts.end());
+            return ts[3];
+        };
+        auto slope = [&](const char *name, auto l1, auto l2) {
+            const float t1 = timeit(l1), t2 = timeit(l2);
+            printf("%-64s T1 %6.2f us  T2 %6.2f us  -> %6.1f ns per k-tile, fixed part %5.2f us\n", name, t1, t2, (t2 - t1) / 64 * 1000.f, t1 - (t2 - t1));
+            fflush(stdout);
+        };
+        slope("v2 [n][k]", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, 1000); },
+                           [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, 2000); });
+        slope("ws2 full [n][k]", [&] { WS2(5, false, 4, 0, 0, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 0, B, K, 2000); });
+        slope("ws2 INTERLEAVED reads, full [n][k]", [&] { WS2(5, false, 4, 0, 6, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 6, B, K, 2000); });
+        slope("ws2 INTERLEAVED reads, full [k][n]", [&] { WS2(5, true, 4, 0, 6, Bt, N, 1000); }, [&] { WS2(5, true, 4, 0, 6, Bt, N, 2000); });
+        slope("ws2 INTERLEAVED reads, no DMA", [&] { WS2(5, false, 4, 0, 7, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 7, B, K, 2000); });
+        slope("ws2 INTERLEAVED, ring 4", [&] { WS2(4, false, 4, 0, 6, B, K, 1000); }, [&] { WS2(4, false, 4, 0, 6, B, K, 2000); });
+        slope("ws2 INTERLEAVED, ring 6", [&] { WS2(6, false, 4, 0, 6, B, K, 1000); }, [&] { WS2(6, false, 4, 0, 6, B, K, 2000); });
+        slope("ws2 INTERLEAVED, 2 producers", [&] { WS2(5, false, 2, 0, 6, B, K, 1000); }, [&] { WS2(5, false, 2, 0, 6, B, K, 2000); });
+        slope("ws2 no DMA", [&] { WS2(5, false, 4, 0, 1, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 1, B, K, 2000); });
+        slope("ws2 no fragment reads", [&] { WS2(5, false, 4, 0, 2, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 2, B, K, 2000); });
+        slope("ws2 MFMAs only (no DMA, no reads, no barriers)", [&] { WS2(5, false, 4, 0, 3, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 3, B, K, 2000); });
+        slope("ws2 MFMAs + barriers", [&] { WS2(5, false, 4, 0, 4, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 4, B, K, 2000); });
+        slope("ws2 MFMAs + reads (no DMA, no barriers)", [&] { WS2(5, false, 4, 0, 5, B, K, 1000); }, [&] { WS2(5, false, 4, 0, 5, B, K, 2000); });
+    }
+    if (getenv("WS_ROUND1"))
     for (int pass = 0; pass < 2; ++pass) {
         printf("---- pass %d\n", pass);
         run("v2 (rounds 4-5) [n][k] warm", [&] { hipLaunchKernelGGL((gemm_dma_v2<4, false, 2>), dim3(tm * tn), dim3(256), 0, st, A, B, C, K, K, N, K, tm, tn, 0); });
