@@ -315,6 +315,7 @@ int main(int argc, char **argv)
         // consumes: this rank's rows of every global minibatch
         if (!P.stack_on_device && lead) fprintf(log, "(gpu_used > 1: stack=host is not used, the context windows are built on the device)\n");
         ring->register_rank(rank);                          // (peers notice this process dying without its atexit hook)
+        { const unsigned hw = std::thread::hardware_concurrency(); reader.set_convert_threads(hw > (unsigned)world ? (int)(hw / (unsigned)world) : 1); }   // every rank converts at once: cores / ranks workers each
         const bool ring_pinned = bp_host_register(ring->base(), ring->bytes()) == 0;      // (per process: after the fork)
         if (!ring_pinned) fprintf(stderr, "bptrain: rank %d could not pin the shared chunk ring (%s); its uploads will be staged copies\n", rank, bp_last_error());
         std::thread helper([&] {

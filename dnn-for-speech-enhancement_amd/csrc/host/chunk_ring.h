@@ -87,6 +87,10 @@ public:
         hdr_->abort.store(1);
     }
     bool aborted() const { return hdr_->abort.load() != 0; }
+    // where this rank's producer thread spent its time, seconds (tools/reader_ring_bench.cc): waiting for the slot to be consumed |
+    // building the tables (rank 0) | waiting for the tables | converting its slice | waiting for the other slices (rank 0) | noise-aware rows
+    struct Times { double wait_slot = 0, tables = 0, wait_tables = 0, convert = 0, wait_converted = 0, nat = 0; };
+    const Times &times() const { return times_; }
 
     // The producer side of chunk number `seq` of the epoch (plan chunk `chunk_index`), run by EVERY rank in order
     // seq = 0, 1, ... on a helper thread: rank 0 publishes the tables, everyone converts a slice, rank 0 finishes.
@@ -98,29 +102,37 @@ public:
         int *ws = (int *)(nat + (size_t)ncap_ * D_), *tf = ws + scap_, *nr = tf + scap_;
         const PfileReader::ChunkShape c = r.chunk_shape(p, chunk_index);
         if (c.n_frames > fcap_ || c.n_samples > scap_) { fail("chunk ring: chunk " + std::to_string(chunk_index) + " exceeds the planned capacity"); return false; }
+        double tk = clock_s();
+        auto lap = [&](double &acc) { const double n = clock_s(); acc += n - tk; tk = n; };
         if (rank == 0) {
             if (!wait([&] { return s.consumed.load() == world_; })) return false;       // previous tenant fully consumed
+            lap(times_.wait_slot);
             s.converted.store(0); s.consumed.store(0);
             std::vector<int> seg_start, seg_sent;
             r.build_tables(p, chunk_index, shuffle, ws, tf, r.nat() ? nr : nullptr, seg_start, seg_sent);
+            lap(times_.tables);
             if ((int)seg_start.size() > ncap_ && r.nat()) { fail("chunk ring: more noise-aware rows than planned"); return false; }
             s.n_samples = c.n_samples; s.n_frames = c.n_frames; s.n_nat = r.nat() ? (int)seg_start.size() : 0;
             seg_start_ = seg_start; seg_sent_ = seg_sent;
             s.tables_seq.store(seq);
         }
         if (!wait([&] { return s.tables_seq.load() == seq; })) return false;
+        lap(times_.wait_tables);
         const int lo = (int)((long)c.n_frames * rank / world_), hi = (int)((long)c.n_frames * (rank + 1) / world_);
         {   // (this runs on a helper thread: no print-and-exit in here, the text goes to the main threads through the header)
             const std::string e = r.try_convert_frames(p, chunk_index, c.frame_st, lo, hi, fea, targ);
             if (!e.empty()) { fail(e); return false; }
         }
+        lap(times_.convert);
         s.converted.fetch_add(1);
         if (rank == 0) {
             if (!wait([&] { return s.converted.load() == world_; })) return false;
+            lap(times_.wait_converted);
             if (r.nat() && c.n_frames > 0) {
                 const std::string e = r.try_nat_rows(p, chunk_index, fea, seg_start_, seg_sent_, nat);
                 if (!e.empty()) { fail(e); return false; }
             }
+            lap(times_.nat);
             s.ready_seq.store(seq);
         }
         return true;
@@ -177,6 +189,8 @@ private:
         }
         return true;
     }
+    static double clock_s() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+    Times times_;
     int world_, fcap_, scap_, ncap_, D_, OD_;
     double timeout_s_ = 150.0;
     size_t slot_floats_, slot_bytes_, bytes_;

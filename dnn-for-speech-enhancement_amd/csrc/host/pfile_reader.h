@@ -28,6 +28,8 @@ public:
     ~PfileReader();
     // Interface::get_pfile_info (Interface.cc:468-555): headers, sentence tables, consistency checks
     void open();
+    // worker threads of one frame conversion (0 = up to 8, the single-reader default); the node-level ring sets cores / ranks
+    void set_convert_threads(int n) { convert_threads_ = n; }
     // Interface::get_chunk_info[_cv] (Interface.cc:558-686): plan chunks over sentences [st, en] (inclusive)
     struct Plan {
         std::vector<int> chunk_frame_st; int sent_st = 0, sent_en = 0; unsigned total_samples = 0;
@@ -91,6 +93,7 @@ private:
     unsigned total_frames_ = 0, total_sents_ = 0;
     std::vector<int> frames_before_sent_;
     std::vector<float> mean_, dvar_;
+    int convert_threads_ = 0;
     bool nat_ = false;
     bool clamp_warned_ = false;
 };
