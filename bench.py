@@ -303,17 +303,23 @@ def windows_line(dnnse_amd, dev, n=51200, reps=3):
 def dp_world1_line(dnnse_amd, dev, W, b, steps=600):
     """C2 through the data-parallel exchange path with a group of ONE rank (all that one GPU can time): gradient store ->
     flags -> sharded update on the exchange stream -> weights gathered before the next forward (bp_dp_attach), against the
-    fused single-device step.  The gap is what the exchange machinery costs before any byte crosses xGMI."""
+    fused single-device step.  The gap is what the exchange machinery costs before any byte crosses xGMI.  The line is the default
+    exchange (reduce-scatter by peer reads); `push_form` beside it is the same step with the reduce-scatter by peer writes
+    (transport 2), which at world 1 pays one more pass over the gradient segments (local copy into the receive slot)."""
     chunk = 100 * BUNCH
-    g = dnnse_amd.BP_GPU(1, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, device=dev, max_chunk_frames=chunk, dropoutflag=1,
-                         visible_omit=0.1, hid_omit=0.2, seed=20260927, global_bunchsize=BUNCH, rank_frame_offset=0)
-    g.dp_attach(1, 0, "bench-w1-%d-%d" % (os.getpid(), int(time.time())))
-    g.fill_chunk_synthetic(chunk, 20260927)
-    dt = _timed_resident(g, BUNCH, chunk, steps)
-    g.dp_detach()
-    g.close()
+    out = {}
+    for name, tr in (("pull", 0), ("push", 2)):
+        g = dnnse_amd.BP_GPU(1, len(LAYERS), LAYERS, BUNCH, 1.0, 0.5, 0.0, W, b, device=dev, max_chunk_frames=chunk, dropoutflag=1,
+                             visible_omit=0.1, hid_omit=0.2, seed=20260927, global_bunchsize=BUNCH, rank_frame_offset=0)
+        g.dp_attach(1, 0, "bench-w1-%s-%d-%d" % (name, os.getpid(), int(time.time())), transport=tr)
+        g.fill_chunk_synthetic(chunk, 20260927)
+        out[name] = _timed_resident(g, BUNCH, chunk, steps)
+        g.dp_detach()
+        g.close()
+    dt = out["pull"]
     return {"workload": "C2 (as the headline line) through the in-library exchange path, world size 1, 1 GPU", "dtype": "f32",
-            "ms_per_step": 1e3 * dt, "value": BUNCH / dt, "unit": "frames/s", "steps": steps}
+            "ms_per_step": 1e3 * dt, "value": BUNCH / dt, "unit": "frames/s", "steps": steps,
+            "push_form": {"ms_per_step": 1e3 * out["push"], "value": BUNCH / out["push"], "unit": "frames/s"}}
 
 
 def c1_end_to_end_line():
@@ -372,7 +378,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the C5 line, the measured peaks and the live counter passes")
     ap.add_argument("--sustained-s", type=float, default=4.0, help="seconds of the additional sustained-rate measurement (0 = skip)")
     ap.add_argument("--chunk", type=int, default=CHUNK)
-    ap.add_argument("--exchange", choices=["both", "native", "rccl"], default="both",
+    ap.add_argument("--exchange", choices=["all", "both", "native", "native_push", "rccl"], default="all",
                     help="transport of the data-parallel exchange (N > 1): the library's peer kernels, RCCL reduce-scatter/all-gather, or "
                          "(default) BOTH timed back to back in this one run, the faster one being the line's value")
     ap.add_argument("--force-dp", action="store_true", help="run the exchange path at N = 1 (world-1 group)")
@@ -472,6 +478,33 @@ def live_pmc(counters, timeout_s=150.0):
     return {k: {c: statistics.median(v) for c, v in cs.items()} for k, cs in acc.items()} or None
 
 
+def live_kernel_stats(timeout_s=150.0):
+    """One `rocprofv3 --kernel-trace --stats` pass over a short run of THIS script (the C2 headline steps, no extras), on this box, now:
+    {kernel name: (average ns, calls)} or None.  The HEADLINE roofline figure is the dominant kernel's average from this pass."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", td, "-o", "kt", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-extras", "--prewarm-s", "0.5", "--sustained-s", "0", "--chunk", "5120"]
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["TMPDIR"] = "/tmp"
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        except Exception:
+            return None
+        out = {}
+        for f in glob.glob(os.path.join(td, "**", "*kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                out[r["Name"]] = (float(r["AverageNs"]), int(r["Calls"]))
+    return out or None
+
+
 def _pick(pmc, pred):
     for k, v in (pmc or {}).items():
         if pred(k):
@@ -485,6 +518,13 @@ def live_counters():
     is_wgrad = lambda k: k.startswith("void bp_wgrad_dma<16, 4, 4, 256, false>")          # noqa: E731
     is_hidden = lambda k: k.startswith("void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 0>")   # noqa: E731  (EPI 0 = hidden forward, TAG 0 = layers 2..L-2)
     out = {}
+    ks = live_kernel_stats()
+    if ks:
+        k = next((n for n in ks if is_wgrad(n)), None)
+        if k:
+            out["wgrad_kernel_ns"] = ks[k][0]
+            out["wgrad_kernel_calls"] = ks[k][1]
+        out["kernel_avg_us"] = {n.split("(")[0][:72]: round(v[0] * 1e-3, 3) for n, v in ks.items() if v[1] >= 100}
     fe, wr = live_pmc(["FETCH_SIZE"]), live_pmc(["WRITE_SIZE"])
     kf, vf = _pick(fe, is_wgrad)
     kw, vw = _pick(wr, is_wgrad)
@@ -510,8 +550,9 @@ def live_counters():
 def committed_mfma_util():
     """profiles/r05_mfma_util.json (tools/pmc_sq_summary.py): the same ratio from the committed SQ pass, with its source stamp."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r05_mfma_util.json")))
-        return {"source": "profiles/r05_mfma_util.json", "sources_sha": j.get("sources_sha"),
+        name = next(f for f in ("r06_mfma_util.json", "r05_mfma_util.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return {"source": "profiles/" + name, "sources_sha": j.get("sources_sha"),
                 "matches_current_kernel_sources": j.get("sources_sha") == kernel_source_stamp(), "kernels": j.get("kernels")}
     except Exception:
         return None
@@ -564,7 +605,11 @@ def main():
     import dnnse_amd
 
     dp = world > 1 or args.force_dp or os.environ.get("BENCH_FORCE_DP") == "1"
-    plan = (["native", "rccl"] if args.exchange == "both" else [args.exchange]) if world > 1 else (["native" if args.exchange == "both" else args.exchange] if dp else [])
+    # N > 1: every exchange the library has, timed in ONE run -- native (reduce-scatter by peer reads), native_push (by peer writes into
+    # the owners' receive buffers), rccl; "both" = the two of round 5 (native, rccl)
+    every = ["native", "native_push", "rccl"]
+    plan = (every if args.exchange == "all" else (["native", "rccl"] if args.exchange == "both" else [args.exchange])) if world > 1 else \
+        (["native" if args.exchange in ("all", "both") else args.exchange] if dp else [])
 
     def group_failed(tr, err):
         """how many ranks failed to attach `tr` (every rank gets the same answer)"""
@@ -694,7 +739,7 @@ def main():
         # The native exchange checks its memory-model assumptions on the group's real devices at attach and refuses to run when they
         # do not hold; RCCL may be missing or refuse the topology.  Either is reported in the line, never fatal while one transport works.
         try:
-            g.dp_attach(world, rank, "%s-%s" % (key, tr), transport=1 if tr == "rccl" else 0)
+            g.dp_attach(world, rank, "%s-%s" % (key, tr), transport={"native": 0, "rccl": 1, "native_push": 2}[tr])
             state["attached"] = True
             return None
         except dnnse_amd.BPError as e:
@@ -721,8 +766,9 @@ def main():
                                    "(global bunch %d), lrate 1, momentum 0.5, %d-frame chunk resident in HBM"
                                    % (BUNCH, BUNCH * world, chunk),
                        "parallelism": "dp%d" % world, "frames_per_gpu_per_step": BUNCH, "global_bunch": BUNCH * world,
-                       "exchange": (("RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)" if chosen == "rccl" else
-                                     "in-library hipIpc reduce-scatter + sharded update + all-gather (bp_dp_attach)") if dp else "none"),
+                       "exchange": ({"rccl": "RCCL reduce-scatter + sharded update + all-gather (bp_dp_attach_ex)",
+                                     "native_push": "in-library hipIpc reduce-scatter by peer WRITES + sharded update + all-gather (bp_dp_attach_ex, push form)"}
+                                    .get(chosen, "in-library hipIpc reduce-scatter by peer reads + sharded update + all-gather (bp_dp_attach)") if dp else "none"),
                        "launcher": "self (bench.py forked its ranks)" if os.environ.get("BENCH_SELF_LAUNCHED") == "1" else
                                    ("torch.distributed.run" if world > 1 else "single process")},
         }
@@ -763,7 +809,7 @@ def main():
         # HBM-side bytes of that launch from the committed PMC pass (tools/profile_r05.sh), stamped with the kernel sources it was
         # taken on; replaced further down by THIS run's own counter passes when they succeed
         traffic, tstamp = None, None
-        for name in ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json"):
+        for name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json"):
             traffic, tstamp = profiled_traffic(name, lambda k: "bp_wgrad_dma" in k and "bf16" not in k and "grid=" in k and int(k.split("grid=")[1]) > 500000)
             if traffic is not None:
                 break
@@ -771,22 +817,30 @@ def main():
         rk_ms, rk_file = None, None
         try:
             import csv
-            rk_file = next(f for f in ("r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            rk_file = next(f for f in ("r06_bench_kernel_stats.csv", "r05_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv") if os.path.exists(os.path.join(ROOT, "profiles", f)))
             for row in csv.DictReader(open(os.path.join(ROOT, "profiles", rk_file))):
                 if row["Name"].startswith("void bp_wgrad_dma<16, 4, 4, 256") and "true" not in row["Name"]:     # (the fused-update form)
                     rk_ms = float(row["AverageNs"]) * 1e-6
         except Exception:
             rk_ms = None
+        # ONE headline definition: roofline.achieved / frac = algorithmic FLOPs of the dominant launch / its rocprofv3
+        # --kernel-trace average / 157.3 TF -- from THIS run's own rocprofv3 pass when it succeeds (further down), else from the committed
+        # summary of the same command, else (no profiler, no file) from the in-step events.  The in-step event figure (kernel + the ~3 us
+        # dependent-launch boundary in front of it) is always reported beside it as `in_step_events`.
+        ev = {"kernel_ms": wg_ms, "achieved": ach, "frac": ach / PEAK_MFMA_F32_TF,
+              "measured_by": "HIP events inside 100 real steps on the launch stream (bp_profile_step): previous event -> own event, i.e. the kernel "
+                             "plus the ~3 us dependent-launch boundary in front of it"}
+        head_ms, head_src = (rk_ms, "profiles/%s (committed rocprofv3 --kernel-trace --stats average of the same command, another box)" % rk_file) if rk_ms \
+            else (wg_ms, "in-step HIP events (no rocprofv3 figure available)")
         res["roofline"] = {
             "bound": "mfma", "kernel": "bp_wgrad_dma<16,4,4,256> (wgrad + fused momentum update of all 4 layers, one grouped launch per step)",
-            "achieved": ach, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TF,
+            "achieved": wg_fl / (head_ms * 1e-3) / 1e12, "peak": PEAK_MFMA_F32_TF, "unit": "TFLOP/s", "frac": wg_fl / (head_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TF,
+            "definition": "algorithmic FLOPs of the launch (2*B*P) / rocprofv3 --kernel-trace average duration of the kernel / 157.3 TFLOP/s",
             "traffic": traffic, "traffic_stamp": tstamp, "algorithmic_flops": wg_fl, "algorithmic_bytes": alg_bytes,
-            "kernel_ms": wg_ms,
-            "rocprof_kernel_ms": rk_ms, "rocprof_frac": (wg_fl / (rk_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TF) if rk_ms else None,
-            "rocprof_source": "profiles/%s (AverageNs of the same kernel under the same command, another box)" % rk_file if rk_ms else None,
-            "measured_by": "HIP events inside 100 real steps on the launch stream (bp_profile_step): previous event -> own event, "
-                                                     "i.e. the kernel plus the ~3 us dependent-launch boundary in front of it; rocprofv3's average of the kernel alone "
-                                                     "(rocprof_kernel_ms) is that much shorter",
+            "kernel_ms": head_ms, "kernel_ms_source": head_src,
+            "in_step_events": ev,
+            "rocprof_committed": {"kernel_ms": rk_ms, "frac": (wg_fl / (rk_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TF) if rk_ms else None,
+                                  "source": "profiles/%s" % rk_file if rk_ms else None},
             "kernels_in_step_ms": {k: v[0] for k, v in prof.items()}, "launches_per_step": {k: v[1] for k, v in prof.items()},
             "hidden_fwd_2048x2048": {"achieved": 2.0 * BUNCH * 2048 * 2048 / (prof["fwd_hidden"][0] * 1e-3) / 1e12,
                                      "frac": 2.0 * BUNCH * 2048 * 2048 / (prof["fwd_hidden"][0] * 1e-3) / 1e12 / PEAK_MFMA_F32_TF,
@@ -799,10 +853,10 @@ def main():
         cm = committed_mfma_util()
         if cm:
             res["roofline"]["mfma_util_committed"] = cm
-            hk = next((v for k, v in (cm.get("kernels") or {}).items() if k.startswith("void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>")), None)
+            hk = next((v for k, v in (cm.get("kernels") or {}).items() if k.startswith(("void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 0>", "void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 1, 0, 0>"))), None)
             if hk:
                 res["roofline"]["hidden_fwd_2048x2048"]["mfma_busy_frac"] = hk.get("mfma_busy_frac")
-                res["roofline"]["hidden_fwd_2048x2048"]["mfma_busy_frac_source"] = "profiles/r05_mfma_util.json"
+                res["roofline"]["hidden_fwd_2048x2048"]["mfma_busy_frac_source"] = cm["source"]
         if not args.no_extras:
             # north_star's GEMM once more from BACK-TO-BACK launches of the same kernel (bp_time_kernel: no event between the
             # launches, so no serialised dispatch in the figure): the number to hold against ">= 60 %"
@@ -819,7 +873,7 @@ def main():
                 res["roofline"]["hidden_fwd_2048x2048"]["back_to_back"] = {"error": str(e)[:200]}
             mf, cp = g.measure_peaks()
             res["roofline"]["peak_measured"] = {"mfma_f32_TFLOPs": mf, "hbm_copy_GBs": cp,
-                                                "frac_of_measured_mfma": ach / mf if mf > 0 else None,
+                                                "frac_of_measured_mfma": res["roofline"]["achieved"] / mf if mf > 0 else None,
                                                 "note": "bare v_mfma_f32_32x32x2_f32 loop and 1 GiB float4 copy, this device, this process"}
     g.close()
     if rank == 0 and not dp and not args.no_extras:
@@ -828,6 +882,16 @@ def main():
             lc = live_counters()
         except Exception as e:
             lc = {"error": str(e)[:200]}
+        if lc.get("wgrad_kernel_ns"):
+            rf = res["roofline"]
+            rf["kernel_ms"] = lc["wgrad_kernel_ns"] * 1e-6
+            rf["kernel_ms_source"] = ("rocprofv3 --kernel-trace --stats pass of `bench.py --steps 200 --warmup 20 --no-extras` run by this process on this box "
+                                      "(%d launches)" % lc["wgrad_kernel_calls"])
+            rf["achieved"] = rf["algorithmic_flops"] / (rf["kernel_ms"] * 1e-3) / 1e12
+            rf["frac"] = rf["achieved"] / PEAK_MFMA_F32_TF
+            rf["kernel_avg_us_this_run"] = lc.get("kernel_avg_us")
+            if isinstance(rf.get("peak_measured"), dict) and rf["peak_measured"].get("mfma_f32_TFLOPs"):
+                rf["peak_measured"]["frac_of_measured_mfma"] = rf["achieved"] / rf["peak_measured"]["mfma_f32_TFLOPs"]
         if lc.get("traffic_bytes"):
             res["roofline"]["traffic_committed"] = {"traffic": res["roofline"]["traffic"], "traffic_stamp": res["roofline"]["traffic_stamp"]}
             res["roofline"]["traffic"] = lc["traffic_bytes"]

@@ -341,7 +341,8 @@ class BP_GPU(object):
 
     # ---- in-library data-parallel exchange (bp_dp_attach, include/bp_c_api.h)
     def dp_attach(self, world, rank, key, transport=0):
-        """transport: 0 = the library's peer kernels over hipIpc mappings, 1 = RCCL reduce-scatter / all-gather."""
+        """transport: 0 = the library's peer kernels over hipIpc mappings (reduce-scatter by peer reads), 1 = RCCL reduce-scatter /
+        all-gather, 2 = the library's peer kernels in push form (every rank writes its slices into the owners' receive buffers)."""
         self._check(self._lib.bp_dp_attach_ex(self._h, int(world), int(rank), str(key).encode(), int(transport)))
 
     def dp_peer_info(self, peer):

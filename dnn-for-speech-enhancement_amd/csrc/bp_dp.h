@@ -214,6 +214,58 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
     }
 }
 
+// Push form of the reduce-scatter (BP_DP_TRANSPORT_NATIVE_PUSH): this rank's gradient segment of one layer, slice by slice, into the
+// owners' receive buffers -- slot `rank` of the layer's region there -- with system-scope write-through 16-byte stores (posted
+// writes over xGMI: nothing waits for a round trip, which is what a reduce-scatter by peer READS does per request); the last
+// workgroup then raises GRAD(layer, rank) in every owner's flag array: "my contribution to your slice has landed".  The owner's
+// bp_dp_reduce_update sums its `world` LOCAL slots in the fixed order 0..world-1 (the pull form's order: same bits).
+struct DpPushArgs {
+    const float *grad;                    // own flat gradient buffer
+    float *recv[BP_DP_MAXRANKS];          // every rank's receive buffer
+    unsigned long long seg;               // flat index of the layer's segment in `grad`
+    unsigned long long n4, per4;          // float4 count of the segment / of one slice (the last slices may be short or empty)
+    unsigned long long roff;              // float index of the layer's region in a receive buffer: `world` slots of 4*per4 floats
+    int world, rank;
+    unsigned *arrive;
+    DpPeers peers; int flag_index; unsigned epoch;
+};
+__global__ __launch_bounds__(256) void bp_dp_push(const DpPushArgs a)
+{
+    const __amdgpu_buffer_rsrc_t rg = bp_rsrc(a.grad + a.seg, (unsigned)(a.n4 * 16));
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (int r = 0; r < a.world; ++r) {
+        const unsigned long long lo = a.per4 * r < a.n4 ? a.per4 * r : a.n4, hi = a.per4 * (r + 1) < a.n4 ? a.per4 * (r + 1) : a.n4;
+        if (hi <= lo) continue;
+        const __amdgpu_buffer_rsrc_t rw = bp_rsrc(a.recv[r] + a.roff + (unsigned long long)a.rank * 4 * a.per4, (unsigned)((hi - lo) * 16));
+        constexpr int U = 4;
+        for (unsigned long long q0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < hi - lo; q0 += U * stride) {
+            bp_f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned long long q = q0 + u * stride < hi - lo ? q0 + u * stride : q0;
+                v[u] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (unsigned)((lo + q) * 16), 0, BP_AUX_SYS));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned long long q = q0 + u * stride;
+                if (q >= hi - lo) break;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v[u]), rw, (unsigned)(q * 16), 0, BP_AUX_SYS);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned last;
+    if (threadIdx.x == 0)
+        last = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last) {
+        if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)threadIdx.x < a.world)
+            __hip_atomic_store(a.peers.flags[threadIdx.x] + a.flag_index, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Momentum slices of the peers into the local arena (bp_get_deltas on a data-parallel handle): plain copy.
 __global__ void bp_dp_copy(float *dst, const float *src, unsigned long long n4)
 {

@@ -40,7 +40,7 @@ extern "C" int bp_rdv_close(bp_rdv *r) { rdv_close(r, false); return BP_OK; }
 // What every rank publishes through the rendezvous block (RdvShm::blob).
 struct DpBlob {
     int device; char pci[20];
-    hipIpcMemHandle_t params, grad, deltas, flags, probe_p, probe_g;
+    hipIpcMemHandle_t params, grad, deltas, flags, probe_p, probe_g, recv;
 };
 static_assert(sizeof(DpBlob) <= BP_RDV_BLOB_BYTES, "rendezvous blob too small");
 
@@ -59,7 +59,11 @@ struct RcclApi {
 struct bp_dp {
     int world, rank;
     bp_rdv *rdv;
-    int backend;                  // 0: native peer kernels over hipIpc mappings | 1: RCCL reduce-scatter / all-gather
+    int backend;                  // 0: native peer kernels over hipIpc mappings (reduce-scatter by peer reads) | 1: RCCL reduce-scatter / all-gather | 2: native, push form
+    bool push;                    // backend 2: gradient slices are WRITTEN into the owners' receive buffers (bp_dp_push)
+    float *recv, *p_recv[BP_DP_MAXRANKS];   // push form: own receive buffer (fine-grained, exported) and every rank's mapping of its own
+    size_t roff[BP_MAXLAYER], per4[BP_MAXLAYER];   // push form: the layer's region in a receive buffer (float index) and float4 per slice slot
+    unsigned *arrive_push;        // [BP_MAXLAYER] last-arriver counters of bp_dp_push
     int acquire_mode;             // 0: kernel boundary behind the wait kernel | 1: + explicit system-scope acquire on every XCD
     bool distinct_devices;        // at least two ranks sit on different physical devices
     int peer_device[BP_DP_MAXRANKS]; char peer_pci[BP_DP_MAXRANKS][20];
@@ -103,7 +107,7 @@ static void dp_release(bp_handle *h, bool failed)
         for (int p = 0; p < d->world; ++p) {
             if (p == d->rank) continue;
             for (void *q : {(void *)d->p_params[p], (void *)d->p_grad[p], (void *)d->p_deltas[p], (void *)d->p_flags[p],
-                            (void *)d->p_probe_p[p], (void *)d->p_probe_g[p]})
+                            (void *)d->p_probe_p[p], (void *)d->p_probe_g[p], (void *)d->p_recv[p]})
                 if (q) (void)hipIpcCloseMemHandle(q);
         }
     for (auto &e : d->ev_g) if (e) (void)hipEventDestroy(e);
@@ -111,7 +115,7 @@ static void dp_release(bp_handle *h, bool failed)
     if (d->ev_comm) (void)hipEventDestroy(d->ev_comm);
     if (d->comm) (void)hipStreamDestroy(d->comm);
     if (d->grad_fine) { if (h->grad == d->grad_fine) h->grad = d->grad_prev; (void)hipFree(d->grad_fine); }
-    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->done, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red})
+    for (void *q : {(void *)d->flags, (void *)d->arrive, (void *)d->done, (void *)d->probe_p, (void *)d->probe_g, (void *)d->red, (void *)d->recv, (void *)d->arrive_push})
         if (q) (void)hipFree(q);
     if (d->err) (void)hipHostFree(d->err);
     rdv_close(d->rdv, failed);
@@ -237,7 +241,7 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     if (!h || !key || !*key) return fail(BP_ERR_ARG, "bp_dp_attach: null argument");
     if (world < 1 || world > BP_DP_MAXRANKS || rank < 0 || rank >= world)
         return fail(BP_ERR_ARG, "bp_dp_attach: world must be 1..8 and 0 <= rank < world");
-    if (transport != BP_DP_TRANSPORT_NATIVE && transport != BP_DP_TRANSPORT_RCCL) return fail(BP_ERR_ARG, "bp_dp_attach: unknown transport");
+    if (transport != BP_DP_TRANSPORT_NATIVE && transport != BP_DP_TRANSPORT_RCCL && transport != BP_DP_TRANSPORT_NATIVE_PUSH) return fail(BP_ERR_ARG, "bp_dp_attach: unknown transport");
     if (transport == BP_DP_TRANSPORT_RCCL && (world & (world - 1)) != 0)
         return fail(BP_ERR_ARG, "bp_dp_attach: the RCCL transport needs a world of 1, 2, 4 or 8 (equal slices)");
     if (h->dp) return fail(BP_ERR_STATE, "bp_dp_attach: handle is already attached");
@@ -250,6 +254,7 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     memset((void *)d, 0, sizeof(*d));
     h->dp = d;
     d->world = world; d->rank = rank; d->epoch = 0; d->peers_open = false; d->backend = transport;
+    d->push = transport == BP_DP_TRANSPORT_NATIVE_PUSH;
     d->budget_ticks = (unsigned long long)(dp_timeout_s() * 1.0e8);      // wall_clock64: 100 MHz
 #define DK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string("bp_dp_attach: ") + #x + ": " + hipGetErrorString(_e); \
         dp_release(h, true); return fail(BP_ERR_DEVICE, m); } } while (0)
@@ -296,13 +301,26 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     }
     DK(hipEventCreateWithFlags(&d->ev_comm, hipEventDisableTiming));
     DK(hipStreamSynchronize(h->stream));
-    size_t max_slice = 4;
+    size_t max_slice = 4, recv_floats = 0;
     for (int l = 1; l < h->L; ++l) {                           // equal float4-aligned slices of [W_l|b_l]
         const size_t cnt4 = h->g_cnt[l] / 4, per4 = (cnt4 + world - 1) / world;
+        d->per4[l] = per4; d->roff[l] = recv_floats; recv_floats += (size_t)world * 4 * per4;
         const size_t a = per4 * rank < cnt4 ? per4 * rank : cnt4, b = per4 * (rank + 1) < cnt4 ? per4 * (rank + 1) : cnt4;
         d->lo[l] = h->g_off[l] + 4 * a; d->hi[l] = h->g_off[l] + 4 * b;
         if (4 * per4 > max_slice) max_slice = 4 * per4;
         if (transport == BP_DP_TRANSPORT_RCCL && per4 * world != cnt4) { dp_release(h, true); return fail(BP_ERR_ARG, "bp_dp_attach: RCCL transport: layer segment not divisible by the world"); }
+    }
+    if (d->push) {
+        // the receive buffer peers WRITE this rank's slice contributions into: fine-grained like the gradient buffer (never cached
+        // dirty; read with system-scope loads), one region per layer of `world` slots
+        if (hipExtMallocWithFlags((void **)&d->recv, (recv_floats + SLACK) * sizeof(float), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            d->recv = nullptr;
+            DK(hipMalloc((void **)&d->recv, (recv_floats + SLACK) * sizeof(float)));
+        }
+        DK(hipMemset(d->recv, 0, (recv_floats + SLACK) * sizeof(float)));
+        DK(hipMalloc((void **)&d->arrive_push, BP_MAXLAYER * sizeof(unsigned)));
+        DK(hipMemset(d->arrive_push, 0, BP_MAXLAYER * sizeof(unsigned)));
     }
     // ---- rendezvous: publish device + hipIpc handles, map every peer's
     {
@@ -319,6 +337,7 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     DK(hipIpcGetMemHandle(&mine.flags, d->flags));
     DK(hipIpcGetMemHandle(&mine.probe_p, d->probe_p));
     DK(hipIpcGetMemHandle(&mine.probe_g, d->probe_g));
+    if (d->push) DK(hipIpcGetMemHandle(&mine.recv, d->recv));
     memcpy(d->rdv->shm->blob[rank], &mine, sizeof(mine));
     if (transport == BP_DP_TRANSPORT_RCCL) {
         DR(dp_load_rccl(d));
@@ -338,7 +357,7 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
         if (strcmp(pb.pci, mine.pci) != 0) d->distinct_devices = true;
         if (p == rank) {
             d->p_params[p] = h->params; d->p_grad[p] = h->grad; d->p_deltas[p] = h->deltas; d->p_flags[p] = d->flags;
-            d->p_probe_p[p] = d->probe_p; d->p_probe_g[p] = d->probe_g;
+            d->p_probe_p[p] = d->probe_p; d->p_probe_g[p] = d->probe_g; d->p_recv[p] = d->recv;
             continue;
         }
         DK(hipIpcOpenMemHandle((void **)&d->p_params[p], pb.params, hipIpcMemLazyEnablePeerAccess));
@@ -347,6 +366,7 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
         DK(hipIpcOpenMemHandle((void **)&d->p_flags[p], pb.flags, hipIpcMemLazyEnablePeerAccess));
         DK(hipIpcOpenMemHandle((void **)&d->p_probe_p[p], pb.probe_p, hipIpcMemLazyEnablePeerAccess));
         DK(hipIpcOpenMemHandle((void **)&d->p_probe_g[p], pb.probe_g, hipIpcMemLazyEnablePeerAccess));
+        if (d->push) DK(hipIpcOpenMemHandle((void **)&d->p_recv[p], pb.recv, hipIpcMemLazyEnablePeerAccess));
     }
     if (rdv_barrier(d->rdv) != 0) { dp_release(h, true); return fail(BP_ERR_STATE, g_rdv_err); }   // every rank has mapped every peer
     if (transport == BP_DP_TRANSPORT_RCCL) {
@@ -439,7 +459,12 @@ static hipError_t dp_reduce_layer(bp_handle *h, int l)
     bp_dp *d = h->dp;
     DpReduceArgs a;
     dp_update_args(h, l, a);
-    for (int p = 0; p < d->world; ++p) { a.grads[p] = d->p_grad[p]; a.params[p] = d->p_params[p]; }
+    for (int p = 0; p < d->world; ++p) {
+        // pull form: slice `rank` of every rank's gradient segment, read over the fabric | push form: this rank's `world` LOCAL
+        // receive slots of the layer (the kernel indexes grads[p] + lo; same summation order 0..world-1 either way)
+        a.grads[p] = d->push ? d->recv + d->roff[l] + (size_t)p * 4 * d->per4[l] - a.lo : d->p_grad[p];
+        a.params[p] = d->p_params[p];
+    }
     const int grid = dp_update_grid(a, l);
     switch (d->world) {
     case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
@@ -448,6 +473,22 @@ static hipError_t dp_reduce_layer(bp_handle *h, int l)
     case 8: hipLaunchKernelGGL(bp_dp_reduce_update<8>, dim3(grid), dim3(256), 0, d->comm, a); break;
     default: hipLaunchKernelGGL(bp_dp_reduce_update<0>, dim3(grid), dim3(256), 0, d->comm, a); break;
     }
+    return hipGetLastError();
+}
+
+// comm stream (push form): this rank's gradient segment of layer l, slice by slice, into the owners' receive buffers; raises GRAD(l, rank) there
+static hipError_t dp_push_layer(bp_handle *h, int l)
+{
+    bp_dp *d = h->dp;
+    DpPushArgs a; memset(&a, 0, sizeof(a));
+    a.grad = h->grad; a.seg = h->g_off[l]; a.n4 = h->g_cnt[l] / 4; a.per4 = d->per4[l]; a.roff = d->roff[l];
+    for (int p = 0; p < d->world; ++p) a.recv[p] = d->p_recv[p];
+    a.world = d->world; a.rank = d->rank; a.arrive = d->arrive_push + l;
+    a.peers = dp_peers(d); a.flag_index = bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank); a.epoch = d->epoch;
+    int grid = (int)((a.n4 + 256 * 4 - 1) / (256 * 4));
+    const int max_grid = l == 1 ? 224 : 128;                   // (the update kernel's sizes: few, deep workgroups beside the GEMMs)
+    if (grid > max_grid) grid = max_grid;
+    hipLaunchKernelGGL(bp_dp_push, dim3(grid < 1 ? 1 : grid), dim3(256), 0, d->comm, a);
     return hipGetLastError();
 }
 
@@ -464,7 +505,8 @@ static hipError_t dp_exchange_layers(bp_handle *h, const int *ls, int n)
         const DpPeers peers = dp_peers(d);
         DpIdx sig, wt; sig.n = wt.n = n;
         for (int i = 0; i < n; ++i) { sig.index[i] = bp_dp_flag_index(BP_DP_FLAG_GRAD, ls[i], d->rank); wt.index[i] = bp_dp_flag_index(BP_DP_FLAG_GRAD, ls[i], 0); }
-        hipLaunchKernelGGL(bp_dp_signal_n, dim3(1), dim3(64), 0, d->comm, peers, d->world, sig, d->epoch);
+        if (d->push) { for (int i = 0; i < n; ++i) if ((er = dp_push_layer(h, ls[i])) != hipSuccess) return er; }   // (each push raises its own flags)
+        else hipLaunchKernelGGL(bp_dp_signal_n, dim3(1), dim3(64), 0, d->comm, peers, d->world, sig, d->epoch);
         hipLaunchKernelGGL(bp_dp_wait_n, dim3(1), dim3(64), 0, d->comm, d->flags, wt, d->world, d->epoch, d->budget_ticks, d->err, 1u);
     }
     for (int i = 0; i < n; ++i) {
@@ -526,6 +568,15 @@ hipError_t dp_bunch(bp_handle *h, int first)
         for (int l = 1; l < L; ++l) {
             done[l] = d->done + l;
             d->done_target[l] += step_wgrad_tiles(h, l);
+            if (d->push) {
+                // wait for the local tiles only (world 0: nothing signalled, nobody waited for), push the slices (raises GRAD at the owners),
+                // wait for every source's contribution to this rank's slice
+                hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + l, d->done_target[l], peers, d->flags, 0,
+                                   bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->epoch, d->budget_ticks, d->err, 1u);
+                CKE(hipGetLastError());
+                CKE(dp_push_layer(h, l));
+                hipLaunchKernelGGL(bp_dp_wait, dim3(1), dim3(64), 0, d->comm, d->flags, bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->world, d->epoch, d->budget_ticks, d->err, 1u);
+            } else
             hipLaunchKernelGGL(bp_dp_sync, dim3(1), dim3(64), 0, d->comm, d->done + l, d->done_target[l], peers, d->flags, d->world,
                                bp_dp_flag_index(BP_DP_FLAG_GRAD, l, d->rank), bp_dp_flag_index(BP_DP_FLAG_GRAD, l, 0), d->epoch, d->budget_ticks, d->err, 1u);
             CKE(hipGetLastError());

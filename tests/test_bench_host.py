@@ -88,12 +88,14 @@ def test_multi_gpu_line_times_both_transports_and_takes_the_faster():
     """north_star names RCCL, the library's default transport is its own peer kernels -- `bench.py --gpus N`
     alone must answer which is faster.  The selection flow (run_exchanges) is walked here with stand-in timings: both
     transports attached by the whole group, timed, detached; value = the faster one."""
-    j = _launch_check(extra_env={"BENCH_FAKE_MS": "native:0.31,rccl:0.29"})
+    j = _launch_check(extra_env={"BENCH_FAKE_MS": "native:0.31,native_push:0.30,rccl:0.29"})
     ex = j["exchange"]
-    assert ex["native"]["ms_per_step"] == 0.31 and ex["rccl"]["ms_per_step"] == 0.29 and ex["chosen"] == "rccl"
-    assert j["detaches"] == [["detach", "native", False], ["detach", "rccl", False]]
-    j = _launch_check(extra_env={"BENCH_FAKE_MS": "native:0.25,rccl:0.29"})
+    assert ex["native"]["ms_per_step"] == 0.31 and ex["native_push"]["ms_per_step"] == 0.30 and ex["rccl"]["ms_per_step"] == 0.29 and ex["chosen"] == "rccl"
+    assert j["detaches"] == [["detach", "native", False], ["detach", "native_push", False], ["detach", "rccl", False]]
+    j = _launch_check(extra_env={"BENCH_FAKE_MS": "native:0.25,native_push:0.27,rccl:0.29"})
     assert j["exchange"]["chosen"] == "native"
+    j = _launch_check(extra_env={"BENCH_FAKE_MS": "native:0.25,native_push:0.24,rccl:0.29"})
+    assert j["exchange"]["chosen"] == "native_push"                  # (VERDICT r5 item 6c: all three exchanges in one run)
 
 
 def test_a_transport_that_one_rank_cannot_attach_is_skipped_by_the_whole_group():
@@ -101,7 +103,7 @@ def test_a_transport_that_one_rank_cannot_attach_is_skipped_by_the_whole_group()
     leaves the broken group, nobody times that transport, the other one supplies the line."""
     j = _launch_check(extra_env={"BENCH_FAKE_FAIL": "native:1"})
     ex = j["exchange"]
-    assert "error" in ex["native"] and "1 rank" in ex["native"]["error"] and ex["chosen"] == "rccl" and "ms_per_step" in ex["rccl"]
+    assert "error" in ex["native"] and "1 rank" in ex["native"]["error"] and ex["chosen"] in ("native_push", "rccl") and "ms_per_step" in ex["rccl"]
     assert j["detaches"][0] == ["detach", "native", True]          # rank 0's log: it had attached and backed out
 
 
@@ -148,9 +150,15 @@ def test_live_counter_passes_are_parsed_into_traffic_and_mfma_busy_fraction(tmp_
     fake.write_text("""#!/usr/bin/env python3
 import os, sys
 a = sys.argv[1:]
-counters = a[a.index("--pmc") + 1:a.index("--output-format")]
 d = a[a.index("-d") + 1]
 os.makedirs(os.path.join(d, "host", "1"), exist_ok=True)
+if "--kernel-trace" in a:
+    with open(os.path.join(d, "host", "1", "kt_kernel_stats.csv"), "w") as f:
+        f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\\n')
+        f.write('"void bp_wgrad_dma<16, 4, 4, 256, false>(MultiArgs)",220,17138000,77900.0,32.8,75641,99561,1482.0\\n')
+        f.write('"void bp_gemm<32, 64, 64, 1, 2, true, false, 0, 0>(GemmArgs, EpiArgs)",440,9724000,22100.0,19.2,20840,37561,939.2\\n')
+    sys.exit(0)
+counters = a[a.index("--pmc") + 1:a.index("--output-format")]
 vals = {"FETCH_SIZE": [92000.0, 92700.0, 92800.0], "WRITE_SIZE": [116000.0, 116800.0, 117000.0],
         "SQ_VALU_MFMA_BUSY_CYCLES": [120.0e6, 120.0e6, 120.0e6], "SQ_BUSY_CU_CYCLES": [42.0e6, 43.0e6, 50.0e6]}
 with open(os.path.join(d, "host", "1", "p_counter_collection.csv"), "w") as f:
@@ -165,6 +173,7 @@ with open(os.path.join(d, "host", "1", "p_counter_collection.csv"), "w") as f:
     one = bench.live_pmc(["FETCH_SIZE"])
     assert one["void bp_wgrad_dma<16, 4, 4, 256, false> grid=933888"]["FETCH_SIZE"] == 92700.0
     lc = bench.live_counters()
+    assert lc["wgrad_kernel_ns"] == 77900.0 and lc["wgrad_kernel_calls"] == 220      # the headline figure: rocprofv3 --kernel-trace average
     assert lc["traffic_bytes"] == (2 * 92700.0 + 116800.0) * 1024.0
     assert abs(lc["mfma_util"]["wgrad_update_grouped"]["mfma_busy_frac"] - 120.0e6 / (4 * 43.0e6)) < 1e-12
     assert abs(lc["mfma_util"]["hidden_fwd_2048x2048"]["mfma_busy_frac"] - 30.0e6 / (4 * 10.75e6)) < 1e-12

@@ -27,6 +27,12 @@ CASES = [
     ("nat4_classic", [1548, 256, 192, 129], 16, 4, 4, {"drop": True, "rule": 1}),
     ("c4_8x256", [2827, 2048, 2048, 2048, 257], 256, 8, 2, {"beta": 0.5}),           # configs[3], real shape
     ("c2_world1", [2827, 2048, 257], 256, 1, 2, {"drop": True}),                     # exchange path with a single rank
+    # BP_DP_TRANSPORT_NATIVE_PUSH (transport 2): the reduce-scatter by peer WRITES into the owners' receive buffers
+    ("push_tiny2", [12, 7, 5, 3], 4, 2, 4, {"transport": 2}),
+    ("push_odd3_dropout_unaligned", [70, 65, 130, 33], 25, 3, 3, {"drop": True, "wc": 0.01, "act": 1, "tail": 31, "transport": 2}),
+    ("push_c4_8x256", [2827, 2048, 2048, 2048, 257], 256, 8, 2, {"beta": 0.5, "transport": 2}),   # configs[3], real shape, in-kernel hand-off
+    ("push_c2_world1", [2827, 2048, 257], 256, 1, 2, {"drop": True, "transport": 2}),
+    ("push_bf16_2", [300, 256, 128, 64], 64, 2, 2, {"compute_dtype": 1, "lr": 0.5, "transport": 2}),        # event hand-off
     ("bf16_2", [300, 256, 128, 64], 64, 2, 2, {"compute_dtype": 1, "lr": 0.5}),
     ("bf16_dma_2", [300, 256, 128, 64], 128, 2, 2, {"compute_dtype": 1, "lr": 0.5, "drop": True}),   # bunch 128: the LDS-DMA gradient-store kernel
 ]
@@ -132,7 +138,12 @@ def test_native_dp_matches_global_bunch_oracle(oracle_mod, parity_record, name, 
     # bit-identical ReLU decisions; only the order of the gradient sum over frames differs.  (The unsharded single-device
     # path faces the oracle -- with the ReLU decisions counted -- in tests/test_gpu_parity.py.)
     if world > 1 and not bf:
-        _, _, one = run_case(name + "_1rank", ls, B * world, 1, nb, dict(extra, tail=extra.get("tail", 0)))
+        _, _, one = run_case(name + "_1rank", ls, B * world, 1, nb, dict(extra, tail=extra.get("tail", 0), transport=0))
+        if extra.get("transport") == 2:
+            # the push form sums the same slices in the same order as the pull form: not "close", the SAME bits
+            _, _, pull = run_case(name + "_pull", ls, B, world, nb, dict(extra, transport=0))
+            for k in res[0]:
+                assert np.array_equal(res[0][k], pull[0][k]), (name, "push form differs from pull form", k)
         strict = {}
         for k in res[0]:
             if k in ("epochs", "cv"):
@@ -168,7 +179,7 @@ def test_handoff_mode_is_reported(pkg):
     from oracle import bp_numpy as N
     ls = [70, 64, 33]
     W, b = N.glorot_net(ls, seed=1, beta=1.0)
-    for B, transport, expect in ((128, 0, True), (128, 1, False), (96, 0, False)):
+    for B, transport, expect in ((128, 0, True), (128, 1, False), (96, 0, False), (128, 2, True)):
         g = pkg.BP_GPU(1, 3, ls, B, 1.0, 0.5, 0.0, W, b, max_chunk_frames=2 * B)
         g.dp_attach(1, 0, "handoff-%d-%d-%d" % (os.getpid(), B, transport), transport=transport)
         assert g.dp_handoff() is expect, (B, transport)
