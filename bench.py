@@ -378,7 +378,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="skip the C5 line, the measured peaks and the live counter passes")
     ap.add_argument("--sustained-s", type=float, default=4.0, help="seconds of the additional sustained-rate measurement (0 = skip)")
     ap.add_argument("--chunk", type=int, default=CHUNK)
-    ap.add_argument("--exchange", choices=["all", "both", "native", "native_push", "rccl"], default="all",
+    ap.add_argument("--exchange", choices=["all", "both", "native", "native_push", "native_push_bf16", "rccl"], default="all",
                     help="transport of the data-parallel exchange (N > 1): the library's peer kernels, RCCL reduce-scatter/all-gather, or "
                          "(default) BOTH timed back to back in this one run, the faster one being the line's value")
     ap.add_argument("--force-dp", action="store_true", help="run the exchange path at N = 1 (world-1 group)")
@@ -606,7 +606,8 @@ def main():
 
     dp = world > 1 or args.force_dp or os.environ.get("BENCH_FORCE_DP") == "1"
     # N > 1: every exchange the library has, timed in ONE run -- native (reduce-scatter by peer reads), native_push (by peer writes into
-    # the owners' receive buffers), rccl; "both" = the two of round 5 (native, rccl)
+    # the owners' receive buffers), rccl; "both" = the two of round 5 (native, rccl).  native_push_bf16 (gradient segments rounded to bf16
+    # on the way out: half the bytes, NOT result-equivalent) only on request: it must never become `chosen` by being faster
     every = ["native", "native_push", "rccl"]
     plan = (every if args.exchange == "all" else (["native", "rccl"] if args.exchange == "both" else [args.exchange])) if world > 1 else \
         (["native" if args.exchange in ("all", "both") else args.exchange] if dp else [])
@@ -739,7 +740,7 @@ def main():
         # The native exchange checks its memory-model assumptions on the group's real devices at attach and refuses to run when they
         # do not hold; RCCL may be missing or refuse the topology.  Either is reported in the line, never fatal while one transport works.
         try:
-            g.dp_attach(world, rank, "%s-%s" % (key, tr), transport={"native": 0, "rccl": 1, "native_push": 2}[tr])
+            g.dp_attach(world, rank, "%s-%s" % (key, tr), transport={"native": 0, "rccl": 1, "native_push": 2, "native_push_bf16": 3}[tr])
             state["attached"] = True
             return None
         except dnnse_amd.BPError as e:

@@ -152,7 +152,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bp_rsrc(const void *p, unsigne
 
 // Slice [lo, hi) of one layer: g = sum over ranks (fixed order 0..world-1, so the result does not depend on
 // which rank owns the slice), momentum update of delta/W, new W to every rank.  One thread = 4 floats per pass.
-template <int WORLD>
+// round to nearest even, NaN stays NaN (as bp_bf16.h f2bf) / back
+__device__ __forceinline__ unsigned bp_dp_f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+// GBF16: the sources are bf16 receive slots (push form with bf16 gradient segments): grads[p] are then bf16 arrays indexed like the
+// float ones (element i of the slice at 2*i bytes)
+template <int WORLD, bool GBF16 = false>
 __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
 {
     const int world = WORLD > 0 ? WORLD : a.world;
@@ -160,7 +170,10 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
     __amdgpu_buffer_rsrc_t rg[BP_DP_MAXRANKS], rw[BP_DP_MAXRANKS];
 #pragma unroll
     for (int p = 0; p < BP_DP_MAXRANKS; ++p)
-        if (p < world) { rg[p] = bp_rsrc(a.grads[p] + a.lo, bytes); rw[p] = bp_rsrc(a.params[p] + a.lo, bytes); }
+        if (p < world) {
+            rg[p] = GBF16 ? bp_rsrc(reinterpret_cast<const unsigned short *>(a.grads[p]) + a.lo, bytes / 2) : bp_rsrc(a.grads[p] + a.lo, bytes);
+            rw[p] = bp_rsrc(a.params[p] + a.lo, bytes);
+        }
     const float *w_own = a.params[a.rank] + a.lo;
     float *d_own = a.delta + a.lo;
     const unsigned long long n4 = (a.hi - a.lo) >> 2, stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -177,7 +190,15 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
             d[u] = *reinterpret_cast<const float4 *>(d_own + 4 * q);
 #pragma unroll
             for (int p = 0; p < BP_DP_MAXRANKS; ++p)
-                if (p < world) g[u][p] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg[p], (unsigned)(q * 16), 0, BP_AUX_SYS));
+                if (p < world) {
+                    if constexpr (GBF16) {
+                        typedef unsigned bp_u32x2 __attribute__((ext_vector_type(2)));
+                        const bp_u32x2 h = __builtin_bit_cast(bp_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rg[p], (unsigned)(q * 8), 0, BP_AUX_SYS));
+                        g[u][p].x = __uint_as_float(h.x << 16); g[u][p].y = __uint_as_float(h.x & 0xFFFF0000u);
+                        g[u][p].z = __uint_as_float(h.y << 16); g[u][p].w = __uint_as_float(h.y & 0xFFFF0000u);
+                    } else
+                    g[u][p] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg[p], (unsigned)(q * 16), 0, BP_AUX_SYS));
+                }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -229,6 +250,7 @@ struct DpPushArgs {
     unsigned *arrive;
     DpPeers peers; int flag_index; unsigned epoch;
 };
+template <bool GBF16 = false>
 __global__ __launch_bounds__(256) void bp_dp_push(const DpPushArgs a)
 {
     const __amdgpu_buffer_rsrc_t rg = bp_rsrc(a.grad + a.seg, (unsigned)(a.n4 * 16));
@@ -236,7 +258,9 @@ __global__ __launch_bounds__(256) void bp_dp_push(const DpPushArgs a)
     for (int r = 0; r < a.world; ++r) {
         const unsigned long long lo = a.per4 * r < a.n4 ? a.per4 * r : a.n4, hi = a.per4 * (r + 1) < a.n4 ? a.per4 * (r + 1) : a.n4;
         if (hi <= lo) continue;
-        const __amdgpu_buffer_rsrc_t rw = bp_rsrc(a.recv[r] + a.roff + (unsigned long long)a.rank * 4 * a.per4, (unsigned)((hi - lo) * 16));
+        // (bf16 segments: the same float indices address 2-byte elements, i.e. a slot of half the bytes at half the offset)
+        const __amdgpu_buffer_rsrc_t rw = GBF16 ? bp_rsrc(reinterpret_cast<unsigned short *>(a.recv[r]) + a.roff + (unsigned long long)a.rank * 4 * a.per4, (unsigned)((hi - lo) * 8))
+                                                : bp_rsrc(a.recv[r] + a.roff + (unsigned long long)a.rank * 4 * a.per4, (unsigned)((hi - lo) * 16));
         constexpr int U = 4;
         for (unsigned long long q0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < hi - lo; q0 += U * stride) {
             bp_f32x4 v[U];
@@ -249,6 +273,12 @@ __global__ __launch_bounds__(256) void bp_dp_push(const DpPushArgs a)
             for (int u = 0; u < U; ++u) {
                 const unsigned long long q = q0 + u * stride;
                 if (q >= hi - lo) break;
+                if constexpr (GBF16) {
+                    typedef unsigned bp_u32x2 __attribute__((ext_vector_type(2)));
+                    bp_u32x2 h;
+                    h.x = bp_dp_f2bf(v[u].x) | (bp_dp_f2bf(v[u].y) << 16); h.y = bp_dp_f2bf(v[u].z) | (bp_dp_f2bf(v[u].w) << 16);
+                    __builtin_amdgcn_raw_buffer_store_b64(h, rw, (unsigned)(q * 8), 0, BP_AUX_SYS);
+                } else
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v[u]), rw, (unsigned)(q * 16), 0, BP_AUX_SYS);
             }
         }

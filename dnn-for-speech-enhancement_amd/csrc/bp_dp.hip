@@ -60,7 +60,8 @@ struct bp_dp {
     int world, rank;
     bp_rdv *rdv;
     int backend;                  // 0: native peer kernels over hipIpc mappings (reduce-scatter by peer reads) | 1: RCCL reduce-scatter / all-gather | 2: native, push form
-    bool push;                    // backend 2: gradient slices are WRITTEN into the owners' receive buffers (bp_dp_push)
+    bool push;                    // backend 2 / 3: gradient slices are WRITTEN into the owners' receive buffers (bp_dp_push)
+    bool gbf16;                   // backend 3: ... rounded to bf16 on the way (half the bytes on the fabric; fp32 sum at the owner)
     float *recv, *p_recv[BP_DP_MAXRANKS];   // push form: own receive buffer (fine-grained, exported) and every rank's mapping of its own
     size_t roff[BP_MAXLAYER], per4[BP_MAXLAYER];   // push form: the layer's region in a receive buffer (float index) and float4 per slice slot
     unsigned *arrive_push;        // [BP_MAXLAYER] last-arriver counters of bp_dp_push
@@ -241,7 +242,7 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     if (!h || !key || !*key) return fail(BP_ERR_ARG, "bp_dp_attach: null argument");
     if (world < 1 || world > BP_DP_MAXRANKS || rank < 0 || rank >= world)
         return fail(BP_ERR_ARG, "bp_dp_attach: world must be 1..8 and 0 <= rank < world");
-    if (transport != BP_DP_TRANSPORT_NATIVE && transport != BP_DP_TRANSPORT_RCCL && transport != BP_DP_TRANSPORT_NATIVE_PUSH) return fail(BP_ERR_ARG, "bp_dp_attach: unknown transport");
+    if (transport < BP_DP_TRANSPORT_NATIVE || transport > BP_DP_TRANSPORT_NATIVE_PUSH_BF16) return fail(BP_ERR_ARG, "bp_dp_attach: unknown transport");
     if (transport == BP_DP_TRANSPORT_RCCL && (world & (world - 1)) != 0)
         return fail(BP_ERR_ARG, "bp_dp_attach: the RCCL transport needs a world of 1, 2, 4 or 8 (equal slices)");
     if (h->dp) return fail(BP_ERR_STATE, "bp_dp_attach: handle is already attached");
@@ -254,7 +255,8 @@ extern "C" int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *ke
     memset((void *)d, 0, sizeof(*d));
     h->dp = d;
     d->world = world; d->rank = rank; d->epoch = 0; d->peers_open = false; d->backend = transport;
-    d->push = transport == BP_DP_TRANSPORT_NATIVE_PUSH;
+    d->push = transport == BP_DP_TRANSPORT_NATIVE_PUSH || transport == BP_DP_TRANSPORT_NATIVE_PUSH_BF16;
+    d->gbf16 = transport == BP_DP_TRANSPORT_NATIVE_PUSH_BF16;
     d->budget_ticks = (unsigned long long)(dp_timeout_s() * 1.0e8);      // wall_clock64: 100 MHz
 #define DK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string("bp_dp_attach: ") + #x + ": " + hipGetErrorString(_e); \
         dp_release(h, true); return fail(BP_ERR_DEVICE, m); } } while (0)
@@ -462,10 +464,13 @@ static hipError_t dp_reduce_layer(bp_handle *h, int l)
     for (int p = 0; p < d->world; ++p) {
         // pull form: slice `rank` of every rank's gradient segment, read over the fabric | push form: this rank's `world` LOCAL
         // receive slots of the layer (the kernel indexes grads[p] + lo; same summation order 0..world-1 either way)
-        a.grads[p] = d->push ? d->recv + d->roff[l] + (size_t)p * 4 * d->per4[l] - a.lo : d->p_grad[p];
+        // (bf16 segments: the kernel treats grads[p] as an array of 2-byte elements with the same indices)
+        a.grads[p] = d->gbf16 ? reinterpret_cast<const float *>(reinterpret_cast<const unsigned short *>(d->recv) + d->roff[l] + (size_t)p * 4 * d->per4[l] - a.lo)
+                              : (d->push ? d->recv + d->roff[l] + (size_t)p * 4 * d->per4[l] - a.lo : d->p_grad[p]);
         a.params[p] = d->p_params[p];
     }
     const int grid = dp_update_grid(a, l);
+    if (d->gbf16) { hipLaunchKernelGGL((bp_dp_reduce_update<0, true>), dim3(grid), dim3(256), 0, d->comm, a); return hipGetLastError(); }
     switch (d->world) {
     case 1: hipLaunchKernelGGL(bp_dp_reduce_update<1>, dim3(grid), dim3(256), 0, d->comm, a); break;
     case 2: hipLaunchKernelGGL(bp_dp_reduce_update<2>, dim3(grid), dim3(256), 0, d->comm, a); break;
@@ -488,7 +493,8 @@ static hipError_t dp_push_layer(bp_handle *h, int l)
     int grid = (int)((a.n4 + 256 * 4 - 1) / (256 * 4));
     const int max_grid = l == 1 ? 224 : 128;                   // (the update kernel's sizes: few, deep workgroups beside the GEMMs)
     if (grid > max_grid) grid = max_grid;
-    hipLaunchKernelGGL(bp_dp_push, dim3(grid < 1 ? 1 : grid), dim3(256), 0, d->comm, a);
+    if (d->gbf16) hipLaunchKernelGGL(bp_dp_push<true>, dim3(grid < 1 ? 1 : grid), dim3(256), 0, d->comm, a);
+    else hipLaunchKernelGGL(bp_dp_push<false>, dim3(grid < 1 ? 1 : grid), dim3(256), 0, d->comm, a);
     return hipGetLastError();
 }
 

@@ -211,8 +211,11 @@ int bp_read_layer_output(bp_handle *h, int layer, float *host_dst, size_t n_floa
  * update, ncclAllGather of the new weights; librccl.so is loaded at run time; world 1, 2, 4 or 8; one rank
  * per device) or BP_DP_TRANSPORT_NATIVE_PUSH (round 6: the native exchange with the reduce-scatter turned round -- every rank
  * WRITES slice r of its gradient segment into rank r's receive buffer with write-through stores, the owner sums its world
- * local slots in the same fixed order; posted writes instead of peer reads on the fabric; same results bit for bit). */
-enum { BP_DP_TRANSPORT_NATIVE = 0, BP_DP_TRANSPORT_RCCL = 1, BP_DP_TRANSPORT_NATIVE_PUSH = 2 };
+ * local slots in the same fixed order; posted writes instead of peer reads on the fabric; same results bit for bit) or
+ * BP_DP_TRANSPORT_NATIVE_PUSH_BF16 (the push form with every rank's contribution rounded to bf16 on the way out: half the bytes on the
+ * fabric, fp32 summation at the owner in the same order; NOT the default for fp32 nets -- it changes results at the 1e-3 level,
+ * tests/test_dp_native.py states and checks its tolerance). */
+enum { BP_DP_TRANSPORT_NATIVE = 0, BP_DP_TRANSPORT_RCCL = 1, BP_DP_TRANSPORT_NATIVE_PUSH = 2, BP_DP_TRANSPORT_NATIVE_PUSH_BF16 = 3 };
 int bp_dp_attach(bp_handle *h, int world, int rank, const char *key);
 int bp_dp_attach_ex(bp_handle *h, int world, int rank, const char *key, int transport);
 int bp_dp_detach(bp_handle *h);     /* collective; also done by bp_destroy */
