@@ -169,7 +169,7 @@ def torch_cpu_line(W, b, budget_s=6.0):
 
 
 def kernel_source_stamp():
-    """sha256[:16] over the kernel sources, as tools/profile_r04.sh stamps its PMC summaries: tells whether a traffic
+    """sha256[:16] over the kernel sources, as tools/profile_r06.sh stamps its PMC summaries: tells whether a traffic
     figure read from profiles/ was measured on the kernels this run executes."""
     import glob
     import hashlib
@@ -218,10 +218,10 @@ def c5_line(dnnse_amd, dev, steps=40):
     # algorithmic bytes per step of the bf16 mode (lower figure): bf16 weights read by fwd and dgrad
     # (2P + 2(P - s0 s1)), fp32 W and delta read + written by the fused update (16P), bf16 shadow refresh (2P)
     alg = 22.0 * P - 2.0 * C5_LAYERS[0] * C5_LAYERS[1]
-    # HBM-side bytes of the step from the committed PMC pass (tools/profile_r04.sh): every kernel of one step summed
+    # HBM-side bytes of the step from the committed PMC pass (tools/profile_r06.sh): every kernel of one step summed
     traffic, tstamp = None, None
     try:
-        c5_file = next(f for f in ("r05_c5_pmc_hbm_traffic.json", "r04_c5_pmc_hbm_traffic.json", "r03_c5_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        c5_file = next(f for f in ("r06_c5_pmc_hbm_traffic.json", "r05_c5_pmc_hbm_traffic.json", "r04_c5_pmc_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
         pm = json.load(open(os.path.join(ROOT, "profiles", c5_file)))
         tot, steps_prof = 0.0, None
         for k, v in pm["kernels"].items():
@@ -807,7 +807,7 @@ def main():
         P = n_params(LAYERS)
         # algorithmic bytes of that launch: W and delta read + written (16P) + every layer's activations and dEdX read once
         alg_bytes = 16.0 * P + 4.0 * BUNCH * (sum(LAYERS[:-1]) + sum(LAYERS[1:]))
-        # HBM-side bytes of that launch from the committed PMC pass (tools/profile_r05.sh), stamped with the kernel sources it was
+        # HBM-side bytes of that launch from the committed PMC pass (tools/profile_r06.sh), stamped with the kernel sources it was
         # taken on; replaced further down by THIS run's own counter passes when they succeed
         traffic, tstamp = None, None
         for name in ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json"):

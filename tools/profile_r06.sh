@@ -1,9 +1,9 @@
-# Round-5 profiles (run on the GPU box through gpurun): rocprofv3 kernel-trace stats of the DRIVER's bench command, separate
+# Round-6 profiles (run on the GPU box through gpurun): rocprofv3 kernel-trace stats of the DRIVER's bench command, separate
 # PMC passes for HBM traffic (FETCH_SIZE / WRITE_SIZE) and SQ counters -- for the fp32 C2 step AND for the bf16 configs[4]
 # per-GPU shape -- each stamped with the sha256 of the kernel sources it was measured on (bench.py compares the stamp with the
-# sources it runs).  New in round 5: profiles/r05_mfma_util.json (tools/pmc_sq_summary.py: MFMA busy over busy-CU cycles).
+# sources it runs).  Also: profiles/r06_mfma_util.json (tools/pmc_sq_summary.py: MFMA busy over busy-CU cycles).
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r05; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r06; rm -rf $O; mkdir -p $O
 STAMP=$(cat $R/dnn-for-speech-enhancement_amd/csrc/*.h $R/dnn-for-speech-enhancement_amd/csrc/*.hip | sha256sum | cut -c1-16)
 cd /tmp && export TMPDIR=/tmp
 SHORT="--steps 40 --warmup 10 --no-cpu-baseline --no-extras --prewarm-s 0 --sustained-s 0"
