@@ -9,6 +9,8 @@
 //     sharded update : delta/W of slice r only (kernUpdatedelta + kernAccSum, DevFunc.cu:313-318,
 //                      270-277) -- the momentum state is never replicated
 //     all-gather     : the new W slice is WRITTEN into every peer's parameter arena
+// (round 6: or, selectable per group, the PUSH form -- every rank WRITES slice r of its segment into rank r's receive buffer,
+// bp_dp_push below, and the owner sums its local slots in the same order: the same bits, posted writes instead of round trips)
 // in ONE kernel (bp_dp_reduce_update), ordered against the peers' kernels by device-side epoch flags:
 // no host synchronisation and no collective library on the data path.  The reference moved the same
 // data through GPU 0 with cublasSaxpy / cublasScopy over P2P (BP_GPU.cu:863-904).
