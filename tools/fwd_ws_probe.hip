@@ -1,0 +1,203 @@
+// tools/fwd_ws_probe.hip -- development probe (round 6; not part of the library): WAVE-SPECIALISED form of the fp32 M = 256 GEMMs of the
+// step (hidden forward 256 x 2048 x 2048 with bias + ReLU + Philox epilogue; hidden dgrad) against the shipped bp_gemm.
+//
+// Shipped form: 4 waves, each stages its share of the next k-tile (global -> registers -> ds_write, transposing the k-contiguous
+// operand) BETWEEN its own MFMAs; one __syncthreads per k-tile; fragment read-ahead restarts behind every barrier.  In-loop it runs at
+// 0.57 us per 64-deep k-tile against 0.456 us of MFMA issue (profiles/r03_gemm_trace_fwd.txt).
+// Here: 4 CONSUMER waves (fragment reads + MFMAs only; read-ahead runs across tile boundaries) + 4 PRODUCER waves (global loads four
+// tiles ahead in four register images, the LDS stores, the counted waits), a ring of 3 LDS stages, one raw s_barrier per k-tile that
+// certifies tile t+1 as stored.  Same k partition and accumulator chains as the shipped kernel => results must be IDENTICAL bits.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/fwd_ws_probe tools/fwd_ws_probe.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "../dnn-for-speech-enhancement_amd/csrc/bp_kernels.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1);} } while (0)
+
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void gemm_ws(const GemmArgs g, const EpiArgs e)
+{
+    using Cfg = GemmCfg<BM, BN, BK, WM, WN, A_KC, B_KC, EPI>;
+    using Regs = typename Cfg::Regs;
+    constexpr int KS = Cfg::KS, TM = Cfg::TM, TN = Cfg::TN, ST = 3;
+    constexpr int A_STAGE = Cfg::A_STAGE, STAGE = Cfg::A_STAGE + Cfg::B_STAGE;
+    constexpr int LDA_S = Cfg::LDA_S, LDB_S = Cfg::LDB_S;
+    static_assert(TM == 1 && TN == 1 && KS == 2, "written for the 32 x 64 tile with the k-tile split between two wave pairs");
+    constexpr int RED = KS * WM * WN * 16 * 64;
+    __shared__ __attribute__((aligned(16))) float smem[ST * STAGE > RED ? ST * STAGE : RED];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n;
+    {
+        const int b = blockIdx.x;
+        if ((g.tiles_n & 7) == 0) { const int xcd = b & 7, j = b >> 3, per = g.tiles_n >> 3; tile_n = xcd * per + j / g.tiles_m; tile_m = j % g.tiles_m; }
+        else { tile_m = b % g.tiles_m; tile_n = b / g.tiles_m; }
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nt = (g.K + BK - 1) / BK, last_k0 = (nt - 1) * BK;
+#define K0_OF(t) (((t) * BK) < last_k0 ? ((t) * BK) : last_k0)
+#define PA(t) Cfg::base_a(g, m0, K0_OF(t))
+#define PB(t) Cfg::base_b(g, n0, K0_OF(t))
+    if (wave >= 4) {
+        // ---------------- producer: 256 threads stage whole k-tiles, exactly the shipped kernel's load / store maps
+        const int ptid = tid - 256;
+        typename Cfg::Offs offs;
+        Cfg::make_offs(offs, g, ptid);
+        float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        Regs r0, r1, r2, r3;                                   // tile t waits in image t % 4
+        Cfg::load(r0, PA(0), PB(0), offs); Cfg::load(r1, PA(1), PB(1), offs); Cfg::load(r2, PA(2), PB(2), offs); Cfg::load(r3, PA(3), PB(3), offs);
+        Cfg::store(r0, smem, smem + A_STAGE, ptid, bsum); Cfg::load(r0, PA(4), PB(4), offs);
+        Cfg::store(r1, smem + STAGE, smem + STAGE + A_STAGE, ptid, bsum); Cfg::load(r1, PA(5), PB(5), offs);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // #0: tiles 0 and 1 are in LDS
+        int sn = 2;                                            // stage of tile i + 2
+        // iteration i (behind barrier #i: the consumers are done with tile i-1, whose stage tile i+2 takes): unrolled by the 4 images
+#define PROD(I, R)                                                                                                   \
+        {                                                                                                            \
+            if (ABL != 1) Cfg::store(R, smem + sn * STAGE, smem + sn * STAGE + A_STAGE, ptid, bsum);                 \
+            Cfg::load(R, PA((I) + 6), PB((I) + 6), offs);                                                            \
+            sn = sn + 1 == ST ? 0 : sn + 1;                                                                          \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+            __builtin_amdgcn_s_barrier();                                                                            \
+        }
+        // the steady-state loop has NO conditionals (a conditional step makes hipcc's waitcnt pass drain vmcnt at the loop header:
+        // measured here first -- 26.6 us, the pipeline emptied every fourth tile)
+        int i = 0;
+        for (; i + 4 <= nt; i += 4) { PROD(i, r2) PROD(i + 1, r3) PROD(i + 2, r0) PROD(i + 3, r1) }
+        if (i < nt) { PROD(i, r2) ++i; }
+        if (i < nt) { PROD(i, r3) ++i; }
+        if (i < nt) { PROD(i, r0) ++i; }
+#undef PROD
+        return;
+    }
+    // ---------------- consumer
+    const int ks = wave / (WM * WN), wq = wave % (WM * WN), wm = wq / WN, wn = wq % WN;
+    const int a_off = wm * TM * 32 + (lane & 31), b_off = wn * TN * 32 + (lane & 31), kh = lane >> 5;
+    const int mb0 = m0 + wm * 32, nb0 = n0 + wn * 32;
+    EpiPre pre;
+    if (ks == 0) epilogue_fetch<EPI, 0, 8>(e, mb0, nb0, lane, pre);
+    if (ks == 1) epilogue_fetch<EPI, 8, 8>(e, mb0, nb0, lane, pre);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    constexpr int NK = BK / KS / 2, RD = 4;
+    const int aoff = (ks * (BK / KS) + kh) * LDA_S + a_off, boff = A_STAGE + (ks * (BK / KS) + kh) * LDB_S + b_off;
+    float av[NK + RD], bv[NK + RD];                            // [NK .. NK+RD): the first fragments of the NEXT tile
+    __builtin_amdgcn_s_barrier();                              // #0
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < RD; ++s) { av[s] = smem[aoff + 2 * s * LDA_S]; bv[s] = smem[boff + 2 * s * LDB_S]; }
+    int sc = 0;
+    for (int t = 0; t < nt; ++t) {
+        const float *cur = smem + sc * STAGE;
+        const int sn = sc + 1 == ST ? 0 : sc + 1;
+        const float *nxt = smem + sn * STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            if (s & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc0, 0, 0, 0);
+            if (ABL != 2) {
+                if (s + RD < NK) { av[s + RD] = cur[aoff + 2 * (s + RD) * LDA_S]; bv[s + RD] = cur[boff + 2 * (s + RD) * LDB_S]; }
+                else { av[s + RD] = nxt[aoff + 2 * (s + RD - NK) * LDA_S]; bv[s + RD] = nxt[boff + 2 * (s + RD - NK) * LDB_S]; }   // (tile t+1: certified by barrier #t)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < RD; ++s) { av[s] = av[NK + s]; bv[s] = bv[NK + s]; }
+        __builtin_amdgcn_s_barrier();                          // #(t+1)
+        sc = sn;
+    }
+#undef K0_OF
+#undef PA
+#undef PB
+    f32x16 acc = acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
+    // in-workgroup k-split exchange + epilogue: the shipped kernel's (the producers have left; s_barrier counts the surviving waves)
+    if (ks == 0) ksplit_give<KS, 0>(acc, smem, wq, lane);
+    if (ks == 1) ksplit_give<KS, 1>(acc, smem, wq, lane);
+    __syncthreads();
+    if (ks == 0) ksplit_take<KS, 0>(acc, smem, wq, lane);
+    if (ks == 1) ksplit_take<KS, 1>(acc, smem, wq, lane);
+    if (ks == 0) epilogue_block<EPI, 0, 8>(e, mb0, nb0, acc, lane, pre);
+    if (ks == 1) epilogue_block<EPI, 8, 8>(e, mb0, nb0, acc, lane, pre);
+}
+
+static float *dalloc(size_t n, float scale, unsigned seed)
+{
+    std::vector<float> h(n);
+    srand(seed);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() / (float)RAND_MAX) * 2.f - 1.f);
+    float *d; CK(hipMalloc(&d, n * 4 + 65536)); CK(hipMemset(d, 0, n * 4 + 65536)); CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+int main()
+{
+    const int B = 256, H = 2048, LD = 2048;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    float *Y = dalloc((size_t)2048 * LD, 1.f, 1), *W = dalloc((size_t)H * LD, 0.03f, 2), *dX = dalloc((size_t)2048 * LD, 0.01f, 5), *bias = dalloc(LD, 0.1f, 6);
+    float *O1 = dalloc((size_t)B * LD, 0.f, 4), *O2 = dalloc((size_t)B * LD, 0.f, 4);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    GemmArgs gf, gd; EpiArgs ef, ed;
+    memset(&gf, 0, sizeof(gf)); memset(&ef, 0, sizeof(ef));
+    gf.A = Y; gf.lda = LD; gf.B = W; gf.ldb = LD; gf.K = H; gf.tiles_m = B / 32; gf.tiles_n = H / 64;
+    ef.ldc = LD; ef.m_limit = B; ef.n_limit = H; ef.n_true = H; ef.bias = bias; ef.alpha = 1.f; ef.drop_thresh = 858993459u; ef.seed_lo = 1; ef.step = 3; ef.layer = 2;
+    memset(&gd, 0, sizeof(gd)); memset(&ed, 0, sizeof(ed));
+    gd.A = dX; gd.lda = LD; gd.B = W; gd.ldb = LD; gd.K = H; gd.tiles_m = B / 32; gd.tiles_n = H / 64;
+    ed.ldc = LD; ed.m_limit = B; ed.n_limit = H; ed.n_true = H; ed.aux = Y; ed.ldaux = LD; ed.alpha = 1.f;
+    std::vector<float> h1((size_t)B * LD), h2((size_t)B * LD);
+    auto timeit = [&](auto launch) {
+        std::vector<float> ts;
+        for (int r = 0; r < 9; ++r) {
+            launch(); launch();
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < 50; ++i) launch();
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / 50 * 1000.f);
+        }
+        std::sort(ts.begin(), ts.end());
+        return ts[4];
+    };
+    auto same = [&]() {
+        CK(hipStreamSynchronize(st)); CK(hipGetLastError());
+        CK(hipMemcpy(h1.data(), O1, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), O2, h2.size() * 4, hipMemcpyDeviceToHost));
+        size_t nd = 0; double mx = 0;
+        for (size_t i = 0; i < h1.size(); ++i) { if (memcmp(&h1[i], &h2[i], 4)) ++nd; mx = std::max(mx, (double)fabsf(h1[i])); }
+        return std::make_pair(nd, mx);
+    };
+    for (int pass = 0; pass < 3; ++pass) {
+        printf("---- pass %d\n", pass);
+        {   // hidden forward
+            EpiArgs a = ef, b = ef; a.C = O1; b.C = O2;
+            CK(hipMemsetAsync(O1, 0, h1.size() * 4, st)); CK(hipMemsetAsync(O2, 0, h2.size() * 4, st));
+            hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>), dim3(256), dim3(256), 0, st, gf, a);
+            hipLaunchKernelGGL((gemm_ws<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>), dim3(256), dim3(512), 0, st, gf, b);
+            auto d = same();
+            const float t1 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>), dim3(256), dim3(256), 0, st, gf, a); });
+            const float t2 = timeit([&] { hipLaunchKernelGGL((gemm_ws<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>), dim3(256), dim3(512), 0, st, gf, b); });
+            const float t3 = timeit([&] { hipLaunchKernelGGL((gemm_ws<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 1>), dim3(256), dim3(512), 0, st, gf, b); });
+            const float t4 = timeit([&] { hipLaunchKernelGGL((gemm_ws<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 2>), dim3(256), dim3(512), 0, st, gf, b); });
+            printf("hidden forward 256x2048x2048: shipped %6.2f us | wave-specialised %6.2f us (%zu of %zu outputs differ, max|y| %.3g) | ws, no LDS stores %6.2f | ws, no fragment reads %6.2f\n",
+                   t1, t2, d.first, h1.size(), d.second, t3, t4);
+        }
+        {   // hidden dgrad, 64-deep k-tiles (the shipped one uses 128-deep: both timed)
+            EpiArgs a = ed, b = ed; a.C = O1; b.C = O2;
+            CK(hipMemsetAsync(O1, 0, h1.size() * 4, st)); CK(hipMemsetAsync(O2, 0, h2.size() * 4, st));
+            hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(256), 0, st, gd, a);
+            hipLaunchKernelGGL((gemm_ws<32, 64, 64, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(512), 0, st, gd, b);
+            auto d = same();
+            const float t0 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 128, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(256), 0, st, gd, a); });
+            const float t1 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(256), 0, st, gd, a); });
+            const float t2 = timeit([&] { hipLaunchKernelGGL((gemm_ws<32, 64, 64, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(512), 0, st, gd, b); });
+            printf("hidden dgrad   256x2048x2048: shipped (128-deep) %6.2f us, 64-deep %6.2f us | wave-specialised 64-deep %6.2f us (%zu outputs differ from the 64-deep one)\n", t0, t1, t2, d.first);
+        }
+        fflush(stdout);
+    }
+    return 0;
+}
