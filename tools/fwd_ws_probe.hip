@@ -197,6 +197,27 @@ int main()
             const float t2 = timeit([&] { hipLaunchKernelGGL((gemm_ws<32, 64, 64, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(512), 0, st, gd, b); });
             printf("hidden dgrad   256x2048x2048: shipped (128-deep) %6.2f us, 64-deep %6.2f us | wave-specialised 64-deep %6.2f us (%zu outputs differ from the 64-deep one)\n", t0, t1, t2, d.first);
         }
+#ifdef BP_PROBE_PK      // needs tools/paired_k_image_probe.patch applied to csrc/bp_kernels.h (the PK template flag is not in the library)
+        {   // paired-k LDS image (bp_kernels.h, PK) in the SHIPPED loop structure
+            EpiArgs a = ef, b = ef; a.C = O1; b.C = O2;
+            CK(hipMemsetAsync(O1, 0, h1.size() * 4, st)); CK(hipMemsetAsync(O2, 0, h2.size() * 4, st));
+            hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>), dim3(256), dim3(256), 0, st, gf, a);
+            hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 0, true>), dim3(256), dim3(256), 0, st, gf, b);
+            auto d = same();
+            const float t1 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN>), dim3(256), dim3(256), 0, st, gf, a); });
+            const float t2 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, false, EPI_FWD_HIDDEN, 0, true>), dim3(256), dim3(256), 0, st, gf, b); });
+            printf("hidden forward, paired-k image of A:        shipped %6.2f us | paired %6.2f us (%zu outputs differ)\n", t1, t2, d.first);
+            EpiArgs c = ed, e2 = ed; c.C = O1; e2.C = O2;
+            CK(hipMemsetAsync(O1, 0, h1.size() * 4, st)); CK(hipMemsetAsync(O2, 0, h2.size() * 4, st));
+            hipLaunchKernelGGL((bp_gemm<32, 64, 128, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(256), 0, st, gd, c);
+            hipLaunchKernelGGL((bp_gemm<32, 64, 128, 1, 2, true, true, EPI_DGRAD, 0, true>), dim3(256), dim3(256), 0, st, gd, e2);
+            auto d2 = same();
+            const float t3 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 128, 1, 2, true, true, EPI_DGRAD>), dim3(256), dim3(256), 0, st, gd, c); });
+            const float t4 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 128, 1, 2, true, true, EPI_DGRAD, 0, true>), dim3(256), dim3(256), 0, st, gd, e2); });
+            const float t5 = timeit([&] { hipLaunchKernelGGL((bp_gemm<32, 64, 64, 1, 2, true, true, EPI_DGRAD, 0, true>), dim3(256), dim3(256), 0, st, gd, e2); });
+            printf("hidden dgrad, paired-k image of A and B:    shipped (128-deep) %6.2f us | paired 128-deep %6.2f us (%zu outputs differ) | paired 64-deep %6.2f us\n", t3, t4, d2.first, t5);
+        }
+#endif
         fflush(stdout);
     }
     return 0;
