@@ -525,6 +525,9 @@ def live_counters():
             out["wgrad_kernel_ns"] = ks[k][0]
             out["wgrad_kernel_calls"] = ks[k][1]
         out["kernel_avg_us"] = {n.split("(")[0][:72]: round(v[0] * 1e-3, 3) for n, v in ks.items() if v[1] >= 100}
+        kh = next((n for n in ks if is_hidden(n)), None)
+        if kh:
+            out["hidden_kernel_ns"] = ks[kh][0]
     fe, wr = live_pmc(["FETCH_SIZE"]), live_pmc(["WRITE_SIZE"])
     kf, vf = _pick(fe, is_wgrad)
     kw, vw = _pick(wr, is_wgrad)
@@ -891,6 +894,15 @@ def main():
             rf["achieved"] = rf["algorithmic_flops"] / (rf["kernel_ms"] * 1e-3) / 1e12
             rf["frac"] = rf["achieved"] / PEAK_MFMA_F32_TF
             rf["kernel_avg_us_this_run"] = lc.get("kernel_avg_us")
+            if lc.get("hidden_kernel_ns"):
+                # north_star's GEMM by the same definition: its rocprofv3 average INSIDE the training step (the in-step event figure,
+                # which carries the launch boundary, moves to in_step_events)
+                hf = rf["hidden_fwd_2048x2048"]
+                hf["in_step_events"] = {"achieved": hf["achieved"], "frac": hf["frac"]}
+                hf["kernel_ms"] = lc["hidden_kernel_ns"] * 1e-6
+                hf["achieved"] = 2.0 * BUNCH * 2048 * 2048 / (hf["kernel_ms"] * 1e-3) / 1e12
+                hf["frac"] = hf["achieved"] / PEAK_MFMA_F32_TF
+                hf["note"] = "north_star's 2048x2048 hidden GEMM: rocprofv3 --kernel-trace average of the kernel inside the training step (this run's own pass)"
             if isinstance(rf.get("peak_measured"), dict) and rf["peak_measured"].get("mfma_f32_TFLOPs"):
                 rf["peak_measured"]["frac_of_measured_mfma"] = rf["achieved"] / rf["peak_measured"]["mfma_f32_TFLOPs"]
         if lc.get("traffic_bytes"):

@@ -714,6 +714,30 @@ def test_public_members_are_live_between_chunks(pkg, oracle_mod):
     g.close()
 
 
+def test_dropout_switched_on_between_chunks_of_a_stacked_handle(pkg, oracle_mod):
+    """Round 6: stacked chunks with visible dropout mask each bunch into the staged tile, which a handle created WITHOUT dropout does not
+    have -- assigning dropoutflag / visible_omit between train() calls (BP_GPU.cu:488-500 reads the public members per bunch) must
+    allocate it on the spot and train exactly like a handle that had dropout from the start; then off again.  Split-K output layer
+    (the next bunch's rows are masked inside the previous bunch's reduce launch) and a narrow one (own launch per bunch)."""
+    for ls, B in (([260, 1024, 70], 64), ([96, 80, 20], 32)):
+        W, b = N.glorot_net(ls, seed=3, beta=1.0)
+        rng = np.random.default_rng(8)
+        x = rng.normal(size=(6 * B, ls[0])).astype(np.float32)
+        t = rng.normal(size=(6 * B, ls[-1])).astype(np.float32)
+        g = _mk(pkg, ls, B, W, b, lr=0.5, seed=21)
+        o = oracle_mod.Oracle(ls, B, 0.5, 0.5, 0.0, W, b, seed=21)
+        g.train(2 * B, x[:2 * B], t[:2 * B]); o.train(x[:2 * B], t[:2 * B])
+        g.dropoutflag, g.visible_omit, g.hid_omit = 1, 0.25, 0.1
+        o.cfg.dropoutflag, o.cfg.visible_omit, o.cfg.hid_omit = 1, 0.25, 0.1
+        g.train(2 * B, x[2 * B:4 * B], t[2 * B:4 * B]); o.train(x[2 * B:4 * B], t[2 * B:4 * B])
+        g.dropoutflag = 0; o.cfg.dropoutflag = 0
+        g.train(2 * B, x[4 * B:], t[4 * B:]); o.train(x[4 * B:], t[4 * B:])
+        w, bb = g.get_weights()
+        for l in range(1, len(ls)):
+            assert relerr(w[l], o.W[l]) < TOL and relerr(bb[l], o.b[l]) < TOL, (ls, l, relerr(w[l], o.W[l]))
+        g.close()
+
+
 def test_visible_mask_over_a_chunk_larger_than_the_old_grid_limit(pkg):
     """A dropout chunk of more than 65535*4 frames used to exceed the y-grid limit of the visible-mask kernel."""
     ls, B, n = [8, 16, 4], 64, 65536 * 4 + 2 * 64
