@@ -74,6 +74,58 @@ def test_full_size_gradient_matches_torch_float64_autograd(pkg, parity_record, l
     assert all(v < TOL for v in worst.values()), worst
 
 
+@pytest.mark.parametrize("ls,drop", [(C2, True), (C3, False)], ids=["C2", "C3"])
+def test_full_size_ten_step_trajectory_matches_torch_float64(pkg, parity_record, ls, drop):
+    """The oracle-FREE counterpart of test_gpu_parity.py::test_full_size_ten_steps_small_lrate_plain_bar: C2 / C3 at real size, TEN training
+    steps at lrate 0.02 / momentum 0.5 on the device against a trajectory computed here in torch float64 -- autograd gradients of the loss
+    written out in tests/torch_ref.py, dropout masks from the test's own numpy Philox, the reference's update rule in float64
+    (delta <- m delta - (1-m) lr (G/n + wc W); W <- W + delta: DevFunc.cu:313-318, 270-277) -- nothing under oracle/ is touched.
+    Outputs of the trained net on fresh frames and every weight matrix at PLAIN 1e-4.  (Momentum state and the zero-initialised biases carry
+    the ReLU-decision effect independently of lrate -- counted and removed exactly in the oracle-based test, recorded raw here.)"""
+    pytest.importorskip("torch")
+    import torch
+    B, L, NS, lr, m, seed = 256, len(ls), 10, 0.02, 0.5, 31
+    W, b = pkg.glorot_net(ls, seed=1, beta=0.5)
+    rng = np.random.default_rng(20261002)
+    x = rng.standard_normal((NS * B, ls[0]), dtype=np.float32)
+    t = rng.standard_normal((NS * B, ls[-1]), dtype=np.float32)
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=seed) if drop else {}
+    g = pkg.BP_GPU(1, L, ls, B, lr, m, 0.0, W, b, max_chunk_frames=NS * B, **kw)
+    g.train(NS * B, x, t)                                            # ONE call: ten bunches back to back
+    w, bb = g.get_weights()
+    dw, dbb = g.get_deltas()
+    xf = rng.standard_normal((300, ls[0]), dtype=np.float32)
+    out_g = g.forward(xf)
+    g.close()
+    W64 = [None] + [np.asarray(W[l], np.float64).copy() for l in range(1, L)]
+    b64 = [None] + [np.asarray(b[l], np.float64).copy() for l in range(1, L)]
+    dW64 = [None] + [np.zeros_like(W64[l]) for l in range(1, L)]
+    db64 = [None] + [np.zeros_like(b64[l]) for l in range(1, L)]
+    c1 = (1.0 - m) * lr
+    for i in range(NS):
+        masks = [drop_mask(seed, i, l, B, ls[l], 0.1 if l == 0 else 0.2) for l in range(L - 1)] if drop else None
+        gw, gb, _, _ = torch_grads(ls, W64, b64, x[i * B:(i + 1) * B], t[i * B:(i + 1) * B], masks)
+        for l in range(1, L):
+            dW64[l] = m * dW64[l] - c1 * (gw[l] / B); W64[l] = W64[l] + dW64[l]
+            db64[l] = m * db64[l] - c1 * (gb[l] / B); b64[l] = b64[l] + db64[l]
+    h = torch.from_numpy(xf.astype(np.float64))                      # CV forward of the trained net (keep-scaled weights, BP_GPU.cu:703-746)
+    for l in range(1, L):
+        keep = (0.9 if l == 1 else 0.8) if drop else 1.0
+        h = keep * (h @ torch.from_numpy(W64[l])) + torch.from_numpy(b64[l])
+        if l < L - 1:
+            h = torch.clamp(h, min=0.0)
+    errs = {"out": relerr(out_g, h.numpy())}
+    for l in range(1, L):
+        errs["W%d" % l] = relerr(w[l], W64[l]); errs["b%d" % l] = relerr(bb[l], b64[l])
+        errs["dW%d" % l] = relerr(dw[l], dW64[l]); errs["db%d" % l] = relerr(dbb[l], db64[l])
+    print("ten steps vs the torch float64 trajectory:", {k: "%.1e" % v for k, v in errs.items()})
+    parity_record(config="C2" if drop else "C3", lrate=lr, momentum=m, steps=NS, reference="torch float64 autograd trajectory + numpy Philox (nothing from oracle/)",
+                  vs_torch_float64=errs, bar="plain 1e-4 on outputs and weight matrices; momentum state and biases recorded (ReLU-decision effect, lrate-independent)")
+    assert errs["out"] < TOL, errs
+    for l in range(1, L):
+        assert errs["W%d" % l] < TOL, (l, errs)
+
+
 def test_bf16_gradient_matches_an_oracle_free_bf16_reference(pkg, parity_record):
     """compute_dtype = 1 (bf16 GEMM operands, fp32 accumulation; BASELINE.json configs[4]'s arithmetic) at bf16's bar of 2e-2
     against a reference that shares nothing with oracle/: the bunch written out by hand in numpy float64 with bf16 rounding at
