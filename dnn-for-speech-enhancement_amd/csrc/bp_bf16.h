@@ -131,6 +131,21 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf1
     for (int b = 0; b < TMB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { in0[b][r] = 0.0f; in1[b][r] = 0.0f; }
+    // dgrad: y_{l-1} of this lane's 16 (32) elements -- UNCONDITIONAL loads from a clamped row and column, in straight-line code,
+    // kept as the raw 16 bits until the epilogue widens them.  (Guarded by m < m_limit and widened on the spot, the compiler emitted
+    // load, s_waitcnt vmcnt(0), shift 32 times in a row: 32 serial round trips in front of the k-loop -- the 5-k-tile output-layer
+    // dgrad of configs[4] took 15.6 us.)
+    if constexpr (EPI == BEPI_DGRAD) {
+        const int nc = n < e.n_limit ? n : e.n_limit - 1;
+#pragma unroll
+        for (int b = 0; b < TMB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = rbase + 32 * b + (r & 3) + 8 * (r >> 2);
+                m = m < e.m_limit ? m : e.m_limit - 1;
+                in0[b][r] = __uint_as_float((uint32_t)e.yprev[(size_t)m * e.ldy + nc]);
+            }
+    }
     if (n < e.n_limit) {
         if constexpr (EPI == BEPI_FWD_HIDDEN || EPI == BEPI_FWD_OUT) bn = e.bias[n];
 #pragma unroll
@@ -140,7 +155,6 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf1
                 const int m = rbase + 32 * b + (r & 3) + 8 * (r >> 2);
                 if (m < e.m_limit) {
                     if constexpr (EPI == BEPI_FWD_OUT) { if (e.C && live) in0[b][r] = e.targ[(size_t)m * e.ldt + n]; }
-                    if constexpr (EPI == BEPI_DGRAD) in0[b][r] = bf2f(e.yprev[(size_t)m * e.ldy + n]);
                     if constexpr (EPI == BEPI_WGRAD_UPDATE) { in0[b][r] = e.W[(size_t)m * e.ldw + n]; in1[b][r] = e.D[(size_t)m * e.ldw + n]; }
                 }
             }
@@ -330,7 +344,7 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf1
         } else if constexpr (EPI == BEPI_DGRAD) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                v[j] = (mq + j < e.m_limit && live) ? act_bwd(e.act, in0[blk][4 * q + j]) * acc[4 * q + j] : 0.0f;
+                v[j] = (mq + j < e.m_limit && live) ? act_bwd(e.act, __uint_as_float(__float_as_uint(in0[blk][4 * q + j]) << 16)) * acc[4 * q + j] : 0.0f;
         } else {                                      // wgrad: rows = units of layer l-1, cols = units of layer l
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

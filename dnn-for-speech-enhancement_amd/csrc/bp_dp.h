@@ -185,6 +185,8 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
     for (unsigned long long q0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; q0 < n4; q0 += U * stride) {
         float4 w[U], d[U];
         bp_f32x4 g[U][BP_DP_MAXRANKS];
+        typedef unsigned bp_u32x2 __attribute__((ext_vector_type(2)));
+        bp_u32x2 gh[GBF16 ? U : 1][BP_DP_MAXRANKS];       // bf16 sources: kept as loaded until the sum (a conversion next to its load makes the compiler wait for every load in turn)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned long long q = q0 + u * stride < n4 ? q0 + u * stride : q0;     // (clamped: loads stay unconditional)
@@ -193,12 +195,8 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
 #pragma unroll
             for (int p = 0; p < BP_DP_MAXRANKS; ++p)
                 if (p < world) {
-                    if constexpr (GBF16) {
-                        typedef unsigned bp_u32x2 __attribute__((ext_vector_type(2)));
-                        const bp_u32x2 h = __builtin_bit_cast(bp_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rg[p], (unsigned)(q * 8), 0, BP_AUX_SYS));
-                        g[u][p].x = __uint_as_float(h.x << 16); g[u][p].y = __uint_as_float(h.x & 0xFFFF0000u);
-                        g[u][p].z = __uint_as_float(h.y << 16); g[u][p].w = __uint_as_float(h.y & 0xFFFF0000u);
-                    } else
+                    if constexpr (GBF16) gh[u][p] = __builtin_bit_cast(bp_u32x2, __builtin_amdgcn_raw_buffer_load_b64(rg[p], (unsigned)(q * 8), 0, BP_AUX_SYS));
+                    else
                     g[u][p] = __builtin_bit_cast(bp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg[p], (unsigned)(q * 16), 0, BP_AUX_SYS));
                 }
         }
@@ -206,6 +204,15 @@ __global__ __launch_bounds__(256) void bp_dp_reduce_update(const DpReduceArgs a)
         for (int u = 0; u < U; ++u) {
             const unsigned long long q = q0 + u * stride;
             if (q >= n4) break;
+            if constexpr (GBF16) {
+#pragma unroll
+                for (int p = 0; p < BP_DP_MAXRANKS; ++p)
+                    if (p < world) {
+                        const bp_u32x2 h = gh[u][p];
+                        g[u][p].x = __uint_as_float(h.x << 16); g[u][p].y = __uint_as_float(h.x & 0xFFFF0000u);
+                        g[u][p].z = __uint_as_float(h.y << 16); g[u][p].w = __uint_as_float(h.y & 0xFFFF0000u);
+                    }
+            }
             bp_f32x4 s = g[u][0];
 #pragma unroll
             for (int p = 1; p < BP_DP_MAXRANKS; ++p)

@@ -758,7 +758,7 @@ __device__ __forceinline__ void stage_rows_block(const StageArgs &a, int bx, int
     float4 v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        v[j] = r0 + j < a.rows ? *reinterpret_cast<const float4 *>(a.fea + (size_t)(r0 + j) * a.fea_dim + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = *reinterpret_cast<const float4 *>(a.fea + (size_t)(r0 + j < a.rows ? r0 + j : a.rows - 1) * a.fea_dim + c);   // (clamped, unconditional: four loads in flight)
     if (a.thresh) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -777,12 +777,21 @@ __device__ __forceinline__ void stage_block(const StageArgs &a, int bx, int by, 
     if (!a.win_start) { stage_rows_block(a, bx, by, tx); return; }
     const int r0 = bx * 4;
     float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // The table entries of the four rows are block-uniform (scalar loads).  Rows past the bunch's end read the LAST row's entry and
+    // data (unconditional, clamped) and are only kept from the stores: guarded per row, every row became s_load, s_waitcnt, load --
+    // four dependent scalar round trips in front of the four row loads of a launch that is nothing but latency.
+    int rr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rr[j] = r0 + j < a.rows ? r0 + j : a.rows - 1;
     if (by >= a.yb_in) {
         const int c = (by - a.yb_in) * 256 + tx;
         if (c >= a.ldt) return;
         if (c < a.twidth) {
+            int tf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) v[j] = a.targ_frames[(size_t)a.targ_frame[r0 + j] * a.twidth + c];
+            for (int j = 0; j < 4; ++j) tf[j] = a.targ_frame[rr[j]];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a.targ_frames[(size_t)tf[j] * a.twidth + c];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) a.t[(size_t)(r0 + j) * a.ldt + c] = v[j];
@@ -792,11 +801,17 @@ __device__ __forceinline__ void stage_block(const StageArgs &a, int bx, int by, 
     if (c >= a.ld) return;
     // all four rows' loads first (independent), the Philox block meanwhile, then the four stores
     if (c < a.win) {
+        int ws[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) v[j] = a.fea[(size_t)a.win_start[r0 + j] * a.fea_dim + c];
+        for (int j = 0; j < 4; ++j) ws[j] = a.win_start[rr[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = a.fea[(size_t)ws[j] * a.fea_dim + c];
     } else if (c < a.width) {
+        int nr[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (r0 + j < a.rows) v[j] = a.nat[(size_t)a.nat_row[r0 + j] * a.fea_dim + (c - a.win)];
+        for (int j = 0; j < 4; ++j) nr[j] = a.nat_row[rr[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = a.nat[(size_t)nr[j] * a.fea_dim + (c - a.win)];
     }
     uint32_t w[4] = {~0u, ~0u, ~0u, ~0u};
     if (a.thresh && c < a.width) drop_words4(w, r0, c, a.frame_off, (uint32_t)a.width, 0u, a.step, a.seed_lo, a.seed_hi);
@@ -841,8 +856,12 @@ __global__ void bp_fill_normal(float *buf, int ld, int width, int rows, uint32_t
 
 // Second half of a split-K output layer: out = sum_z slab[z] + bias; dEdX = scale*(out - targ)
 // (kernSubClean, DevFunc.cu:253-268).  One thread = 4 consecutive columns of one frame.
+// Everything the thread reads -- its four slab pieces, the bias, the targets -- is loaded up front in straight-line code: the launch
+// is pure latency, and with the slab count a run-time loop bound the compiler emitted six DEPENDENT round trips (slab, 3 x (slab,
+// wait, add), bias, targets), which was most of the launch's 5.3 us.
+static constexpr int OUT_SPLITS = 4;
 struct OutReduceArgs {
-    const float *slabs; size_t slab_stride; int nsplit, M, ld, n_true;
+    const float *slabs; size_t slab_stride; int M, ld, n_true;
     const float *bias; float alpha; const float *targ; float scale; float *out, *dedx;
 };
 __device__ __forceinline__ void out_reduce_block(const OutReduceArgs &a, int block, int tx)
@@ -851,18 +870,19 @@ __device__ __forceinline__ void out_reduce_block(const OutReduceArgs &a, int blo
     if (c4 >= a.M * per_row) return;
     const int m = c4 / per_row, n = (c4 % per_row) * 4;
     const size_t i = (size_t)m * a.ld + n;
-    float4 s = *reinterpret_cast<const float4 *>(a.slabs + i);
-    for (int z = 1; z < a.nsplit; ++z) {
-        const float4 p = *reinterpret_cast<const float4 *>(a.slabs + z * a.slab_stride + i);
-        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-    }
+    float4 p[OUT_SPLITS];
+#pragma unroll
+    for (int z = 0; z < OUT_SPLITS; ++z) p[z] = *reinterpret_cast<const float4 *>(a.slabs + z * a.slab_stride + i);
     const float4 b = *reinterpret_cast<const float4 *>(a.bias + n);
+    const float4 t = *reinterpret_cast<const float4 *>(a.dedx ? a.targ + i : a.bias + n);      // (no targets without dEdX: any valid address)
+    float4 s = p[0];
+#pragma unroll
+    for (int z = 1; z < OUT_SPLITS; ++z) { s.x += p[z].x; s.y += p[z].y; s.z += p[z].z; s.w += p[z].w; }
     float o[4] = {a.alpha * s.x + b.x, a.alpha * s.y + b.y, a.alpha * s.z + b.z, a.alpha * s.w + b.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (n + j >= a.n_true) o[j] = 0.0f;
     if (a.out) *reinterpret_cast<float4 *>(a.out + i) = make_float4(o[0], o[1], o[2], o[3]);
     if (a.dedx) {
-        const float4 t = *reinterpret_cast<const float4 *>(a.targ + i);
         float4 d = make_float4(a.scale * (o[0] - t.x), a.scale * (o[1] - t.y), a.scale * (o[2] - t.z), a.scale * (o[3] - t.w));
         if (n + 0 >= a.n_true) d.x = 0.f;
         if (n + 1 >= a.n_true) d.y = 0.f;

@@ -150,7 +150,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     // narrow output layer (e.g. 2048 -> 257): too few 32x32 tiles to fill 256 CUs, so its k range is
     // split over 4 workgroup rows that write partial-sum slabs; bp_out_reduce finishes the layer
     if (h->ld[L - 1] <= 512 && h->ld[L - 2] >= 1024 && h->ld[L - 2] % 256 == 0) {
-        h->out_splits = 4;
+        h->out_splits = OUT_SPLITS;
         // (measured round 3: 8 / 16 k-slices with 64x64 workgroup tiles -- half the operand bytes per FLOP -- are no faster:
         // C2 step 0.2216 ms with 4 slices, 0.2204 with 8, 0.2237 with 16; the layer is launch/latency-bound)
         h->slab_stride = Bp * h->ld[L - 1];
@@ -291,7 +291,7 @@ hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y
         if (er != hipSuccess) return er;
         const int n4 = M * (cur / 4), n_reduce = (n4 + 255) / 256;
         OutReduceArgs ra; memset(&ra, 0, sizeof(ra));
-        ra.slabs = h->slabs; ra.slab_stride = h->slab_stride; ra.nsplit = h->out_splits; ra.M = M; ra.ld = cur; ra.n_true = h->s[l];
+        ra.slabs = h->slabs; ra.slab_stride = h->slab_stride; ra.M = M; ra.ld = cur; ra.n_true = h->s[l];
         ra.bias = h->b[l]; ra.alpha = alpha; ra.targ = targ; ra.scale = e.scale; ra.out = out; ra.dedx = train ? h->dx[l] : (float *)nullptr;
         if (train && h->next_first >= 0 && st == h->stream) {
             // another staged bunch behind this one (window chunk, or stacked chunk with visible dropout): stack / copy (and mask, with the NEXT step's Philox position) that bunch
