@@ -41,6 +41,7 @@ struct BfGemmArgs {
     int lda, ldb, K;           // K: multiple of 64
     int tiles_m, tiles_n;
     int k_rot;                 // LDS-DMA form: k-tile offset between the m-tiles of one n-tile
+    float *ks_slab; unsigned *ks_cnt;   // KS > 1 (k range split over KS workgroups per tile): partial tiles [tile][KS][reg][thread], one ticket word per tile
 };
 struct BfEpiArgs {
     int m_limit, n_limit, n_true;      // rows / cols that exist (padded extents), unpadded column count
@@ -82,10 +83,16 @@ typedef float bf_f32x4 __attribute__((ext_vector_type(4)));
 // measured steps from the register-staged loop (35.5-36.9 us per 512 x 4096 x 4096 GEMM) to this one (22.3-23.3 us).
 template <int N> __device__ __forceinline__ void bf_lgkm3(bf_f32x4 &a, bf_f32x4 &b, bf_f32x4 &c) { asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(a), "+v"(b), "+v"(c) : "n"(N)); }
 template <int N> __device__ __forceinline__ void bf_lgkm4(bf_f32x4 &a, bf_f32x4 &b, bf_v4s &c, bf_v4s &d) { asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N)); }
-template <int EPI, int BM, bool BKN = false, bool DMA = false>
+// KS > 1 (the narrow output layer of configs[4]: 80 tiles of 32 x 64 over K = 4096 are 64 DEPENDENT k-tile round trips on a third of the
+// CUs, 17.7 us): the k range of a tile is split over KS workgroups -- launched next to each other on ONE XCD (block index mod 8), so they
+// meet in one L2 -- that write their fp32 partial tiles (write-through), drain, and take a ticket from the tile's word; the LAST arriver
+// sums the KS partials in the fixed order 0..KS-1 (its own included, from memory: the same bits whoever arrives last) and runs the
+// epilogue.  Nobody waits for anybody.  The ticket words only grow (KS per launch; 2^32 is a multiple of KS).
+template <int EPI, int BM, bool BKN = false, bool DMA = false, int KS = 1>
 __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf16(const BfGemmArgs g, const BfEpiArgs e)
 {
     static_assert(!DMA || BM == 128, "the LDS-DMA loop is written for 128 x 64 tiles");
+    static_assert(KS == 1 || (!DMA && (KS & (KS - 1)) == 0), "split k: register-staged loop, power-of-two split");
     constexpr int NTHR = BM == 32 ? 128 : 256, ROWS = BM + BF_BN, NCHK = ROWS * 8 / NTHR;     // 16-byte chunks per thread and tile
     constexpr int TMB = BM == 128 ? 2 : 1;                                                      // 32x32 blocks per wave along m
     constexpr int NCHK_A = BM * 8 / NTHR;                                                       // chunks i < NCHK_A belong to A, the rest to B
@@ -96,11 +103,16 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf1
     // XCD-aware tile map (block b runs on XCD b % 8): the workgroups that share a B panel (same tile_n, all tile_m)
     // sit on one XCD, so the panel is fetched into that XCD's L2 once instead of eight times
     int tile_m, tile_n;
+    int tile_lin = blockIdx.x, kz = 0;
+    if constexpr (KS > 1) {                                   // groups of 8 tiles x KS slices: slice z of tile 8g+j is block (8*KS)g + 8z + j (the launch has tiles % 8 == 0)
+        const int grp = blockIdx.x / (8 * KS), r = blockIdx.x % (8 * KS);
+        kz = r >> 3; tile_lin = grp * 8 + (r & 7);
+    }
     if ((g.tiles_n & 7) == 0) {
-        const int b = blockIdx.x, xcd = b & 7, jj = b >> 3, per = g.tiles_n >> 3;
+        const int b = tile_lin, xcd = b & 7, jj = b >> 3, per = g.tiles_n >> 3;
         tile_n = xcd * per + jj / g.tiles_m; tile_m = jj % g.tiles_m;
     } else {
-        tile_m = blockIdx.x % g.tiles_m; tile_n = blockIdx.x / g.tiles_m;
+        tile_m = tile_lin % g.tiles_m; tile_n = tile_lin / g.tiles_m;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BF_BN;
     // chunk c of a tile: row c>>3 (rows [0, BM) from A, then BF_BN rows from B), 8 halfs at column (c&7)*8
@@ -117,6 +129,11 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf1
         }
     }
     const size_t bstep = BKN ? (size_t)g.ldb : 1;            // halfs per k of the B operand's source
+    const int nt_all = g.K / BF_BK, kt0 = KS > 1 ? kz * nt_all / KS : 0;
+    if constexpr (KS > 1) {
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) src[i] += (size_t)kt0 * BF_BK * ((BKN && i >= NCHK_A) ? bstep : (size_t)1);
+    }
     // ---- epilogue mapping: lane -> column n, register r -> row (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's 32x32 block
     const int n = n0 + wn * 32 + (lane & 31);
     const int rbase = m0 + wm * 32 * TMB + 4 * (lane >> 5);   // (wm = 0 for BM = 32); block i of the wave: + 32*i
@@ -164,7 +181,7 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf1
     for (int b = 0; b < TMB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accs[b][r] = 0.0f;
-    const int nt = g.K / BF_BK;
+    const int nt = KS > 1 ? (kz + 1) * nt_all / KS - kt0 : nt_all;
     if constexpr (DMA) {
         typedef __attribute__((address_space(3))) void *lds_ptr;
         typedef const __attribute__((address_space(1))) void *glb_ptr;
@@ -309,6 +326,40 @@ __global__ __launch_bounds__(BM == 32 ? 128 : 256, DMA ? 1 : 2) void bp_gemm_bf1
     // is free: every wave is past its last fragment read once the barrier below is passed, and no DMA is in flight.
     constexpr int OC_LD = 72, OT_LD = 136;                    // halfs per row of the staged C [128][64] and CT [64][128] tiles
     bf16_t *oc = smem, *ot = smem + 128 * OC_LD;
+    if constexpr (KS > 1) {
+        constexpr int PART = NTHR * 16 * TMB;                 // floats per partial tile, [reg][thread]
+        float *slab = g.ks_slab + (size_t)tile_lin * KS * PART, *mine = slab + kz * PART;
+#pragma unroll
+        for (int b = 0; b < TMB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(mine + (b * 16 + r) * NTHR + tid, accs[b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned *tk = reinterpret_cast<unsigned *>(smem);    // (the stages are free: the loop ended on a barrier)
+        if (tid == 0) *tk = __hip_atomic_fetch_add(g.ks_cnt + tile_lin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if ((*tk & (KS - 1)) != KS - 1) return;               // not the last of this launch's KS arrivals
+        constexpr int ZG = KS < 4 ? KS : 4;                    // partials in flight per pass (4 x 16 x TMB registers)
+#pragma unroll
+        for (int z0 = 0; z0 < KS; z0 += ZG) {
+            float pz[ZG][TMB][16];
+#pragma unroll
+            for (int z = 0; z < ZG; ++z)
+#pragma unroll
+                for (int b = 0; b < TMB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pz[z][b][r] = __hip_atomic_load(slab + (z0 + z) * PART + (b * 16 + r) * NTHR + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int b = 0; b < TMB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = z0 == 0 ? pz[0][b][r] : accs[b][r] + pz[0][b][r];
+#pragma unroll
+                    for (int z = 1; z < ZG; ++z) s += pz[z][b][r];
+                    accs[b][r] = s;
+                }
+        }
+    }
     if constexpr (DMA) __syncthreads();
     else if (n >= e.n_limit) return;
 #pragma unroll

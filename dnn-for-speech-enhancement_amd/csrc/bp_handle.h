@@ -103,6 +103,7 @@ struct bp_handle {
     bf16_t *Wb[BP_MAXLAYER];                                 // ONE bf16 shadow of the weights, [prev][cur] (the forward reads it through the LDS transpose read)
     bf16_t *yb[BP_MAXLAYER], *ybT[BP_MAXLAYER];              // [Bp][ld_l], [ld_l][Bp]   (l = 0: the input bunch)
     bf16_t *dxb[BP_MAXLAYER], *dxbT[BP_MAXLAYER];
+    float *bf_ks_slab; unsigned *bf_ks_cnt;                  // split-k output forward (bp_bf16.h, KS): partial tiles and ticket words, or null
 };
 
 // Every device buffer gets SLACK floats of zeroed tail so that whole-tile reads of the GEMM loaders (no predicates,

@@ -93,6 +93,8 @@ static int stage_blocks(const bp_handle *h, const StageArgs &a);
 static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs);
 static hipError_t bf_shadow(bp_handle *h, int l);
 
+enum { BF_OUT_KS = 4 };   // (measured at configs[4], us per launch: unsplit 17.7, 4 slices 13.3, 8 slices 13.8, 16 slices 33.3 -- the exchange of the partial tiles grows with the slice count; profiles/r06_bf16_out_split.txt)                                  // k slices of the bf16 output forward (bf_out_splits)
+static bool bf_out_splits(const bp_handle *h);
 extern "C" int bp_create(const bp_config *cfg, const float *const *weights, const float *const *bias,
                          bp_handle **out)
 {
@@ -131,6 +133,7 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     h->in = h->targ = h->out_dev = h->grad = nullptr; h->slabs = nullptr; h->out_splits = 1;
     h->last_ms = 0.f; h->last_bunches = 0; h->dp = nullptr; h->params = h->deltas = nullptr;
     h->next_first = -1; h->pre.valid = false; h->wgen = 0; h->stage_cur = 0;
+    h->bf_ks_slab = nullptr; h->bf_ks_cnt = nullptr;
 
 #define CK(x) do { int _r = (x); if (_r != BP_OK) { std::string m = g_bp_err; bp_destroy(h); g_bp_err = m; return _r; } } while (0)
 #define HK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { std::string m = std::string(#x) + ": " + hipGetErrorString(_e); bp_destroy(h); return fail(BP_ERR_DEVICE, m); } } while (0)
@@ -190,6 +193,14 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
                 CK(bf_alloc(h, &h->Wb[l], nw));
                 HK(bf_shadow(h, l));
             }
+        }
+        // narrow output layer behind a wide one: its forward splits k over BF_OUT_KS workgroups per 32 x 64 tile (bp_bf16.h)
+        const int otiles = (int)(Bp / 32) * (h->ld[L - 1] / 64);
+        if (bf_out_splits(h)) {
+            CK(dev_alloc(h, &h->bf_ks_slab, (size_t)otiles * BF_OUT_KS * 128 * 16));
+            float *cnt = nullptr;
+            CK(dev_alloc(h, &cnt, (size_t)otiles));            // (dev_alloc zeroes)
+            h->bf_ks_cnt = reinterpret_cast<unsigned *>(cnt);
         }
     }
     HK(hipStreamSynchronize(h->stream));
@@ -463,6 +474,13 @@ static hipError_t bf_shadow(bp_handle *h, int l)
     return bf_convert(h, h->W[l], cur, prev, cur, h->Wb[l], cur, nullptr, 0, prev, cur);
 }
 hipError_t step_shadow(bp_handle *h, int l) { return h->bf ? bf_shadow(h, l) : hipSuccess; }
+// The output layer's forward runs split over k when its 32-row tiles are few (less than one per CU), whole groups of 8, and long.
+static bool bf_out_splits(const bp_handle *h)
+{
+    const int L = h->L, tiles = (h->Bp / 32) * (h->ld[L - 1] / 64), nt = h->ld[L - 2] / 64;
+    return h->Bp % 32 == 0 && tiles % 8 == 0 && tiles * BF_OUT_KS <= 2048 && tiles < 256 && nt >= 2 * BF_OUT_KS && nt % BF_OUT_KS == 0 && (h->Bp / 64) * (h->ld[L - 1] / 64) < 512
+           && !(h->Bp % 128 == 0 && (h->Bp / 128) * (h->ld[L - 1] / 64) >= 256);
+}
 // One tile configuration per shape: 128-row tiles while they still give every CU a workgroup (LDS-DMA staged for the
 // hidden forward / dgrad), else 64-row, else 32-row tiles (128-thread workgroups).
 template <int EPI, bool BKN = false>
@@ -493,6 +511,13 @@ static hipError_t bf_launch(bp_handle *h, BfGemmArgs g, const BfEpiArgs &e, int 
         hipLaunchKernelGGL((bp_gemm_bf16<EPI, 64, BKN>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, h->stream, g, e);
     } else {
         g.tiles_m = M / 32;
+        if constexpr (EPI == BEPI_FWD_OUT) {
+            if (h->bf_ks_slab && M == h->Bp && N == h->ld[h->L - 1]) {
+                g.ks_slab = h->bf_ks_slab; g.ks_cnt = h->bf_ks_cnt;
+                hipLaunchKernelGGL((bp_gemm_bf16<EPI, 32, BKN, false, BF_OUT_KS>), dim3(g.tiles_m * g.tiles_n * BF_OUT_KS), dim3(128), 0, h->stream, g, e);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((bp_gemm_bf16<EPI, 32, BKN>), dim3(g.tiles_m * g.tiles_n), dim3(128), 0, h->stream, g, e);
     }
     return hipGetLastError();

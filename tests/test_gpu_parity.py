@@ -598,6 +598,7 @@ BF_CASES = [
     ([300, 1024, 1024, 257], 256, 2, 0, 0, 0.0, True),            # several k-tiles and workgroups per GEMM
     ([70, 130, 64, 20], 128, 2, 1, 1, 0.001, True),               # LDS-DMA wgrad (bunch 128): odd widths, Sigmoid, classic, weight cost
     ([200, 2048, 2048, 40], 1024, 1, 0, 0, 0.0, True),            # bunch 1024: six-wave update launch with 16 k-tiles; LDS-DMA staged GEMMs with 8 m-tiles x 32 n-tiles, K = 2048
+    ([100, 1024, 100], 120, 2, 0, 0, 0.0, True),                  # ragged bunch through the split-k output forward (8 tiles x 4 slices of 4 k-tiles; also cases 4 and 6)
 ]
 
 
