@@ -66,6 +66,7 @@ struct bp_handle {
     float *y[BP_MAXLAYER], *dx[BP_MAXLAYER];
     float *in, *targ, *out_dev;
     float *slabs; size_t slab_stride; int out_splits;   // split-K workspace of the output layer
+    unsigned *out_ticket;                               // ... and its ticket words (one per 32 x 32 output tile)
     float *grad; size_t grad_floats; size_t g_off[BP_MAXLAYER], g_cnt[BP_MAXLAYER];
     float *host_out;             // pinned staging for CV outputs (grow-only, whole chunk)
     float *out_chunk;            // device: network outputs of a whole chunk [frames][ld_L] (CV / forward), grow-only
@@ -87,7 +88,7 @@ struct bp_handle {
     struct { const float *fea, *tg, *nat; const int *ws, *tf, *nr; int D, win; } wv;   // views of set wcur
     float *x0s, *tgs;                         // [Bp][ld_0], [Bp][ld_L]: the staged bunch (= tile stage_cur of the pair below)
     float *x0s2[2], *tgs2[2]; int stage_cur;  // two staged tiles: while bunch i trains out of one, the output layer's reduce launch
-                                              // of bunch i stacks bunch i+1 into the other (bp_out_reduce_stage)
+                                              // of bunch i stacks bunch i+1 into the other (bp_out_split_stage)
     int next_first;                           // chunk frame of the bunch that follows the one being enqueued (-1: none / not a window chunk)
     struct { bool valid; int first, tile; uint32_t step; unsigned gen; } pre;   // what the other tile holds
     unsigned wgen;                            // bumped by every window upload (a pre-staged tile of the old chunk is void)

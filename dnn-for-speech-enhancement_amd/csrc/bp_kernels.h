@@ -33,7 +33,9 @@ __device__ __forceinline__ void static_for(F &&f)
 }
 
 enum { EPI_FWD_HIDDEN = 0, EPI_FWD_OUT = 1, EPI_DGRAD = 2, EPI_WGRAD_UPDATE = 3, EPI_WGRAD_STORE = 4,
-       EPI_PARTIAL = 5 /* raw k-slice partial sums into slab blockIdx.y (split-K) */ };
+       EPI_PARTIAL = 5 /* raw k-slice partial sums into slab blockIdx.y (split-K) */,
+       EPI_OUT_SPLIT = 6 /* split-K output layer in ONE launch: k-slice partials into the slabs, the tile's last arriver sums them and runs EPI_FWD_OUT */ };
+static constexpr int OUT_SPLITS = 4;                       // k-slices of the narrow output layer (EPI_OUT_SPLIT)
 
 // The k-loop loads carry NO predicates (a predicated load makes hipcc drain vmcnt at the top of
 // every iteration, which serialises the prefetch).  Contract with the caller instead:
@@ -52,6 +54,7 @@ struct GemmArgs {
 #endif
     int k_split;             // split-K: workgroup row blockIdx.y handles k in [y*k_split, y*k_split + K)
     size_t slab_stride;      // split-K: floats between the partial-sum slabs of consecutive k-slices
+    float *ks_slab; unsigned *ks_ticket;   // EPI_OUT_SPLIT: the slabs ([slice][m][n], rows ldc apart like the output) and one ticket word per tile
 };
 
 struct EpiArgs {
@@ -174,6 +177,7 @@ __device__ __forceinline__ void epilogue_fetch(const EpiArgs &e, int mb, int nb,
     }
     const int n = nb + (lane & 31);
     const int rbase = mb + 4 * (lane >> 5);
+    static_assert(EPI != EPI_OUT_SPLIT, "fetched as EPI_FWD_OUT");
     if constexpr (EPI == EPI_FWD_HIDDEN || EPI == EPI_FWD_OUT) p.bias = e.bias[n];
     if constexpr (EPI == EPI_FWD_OUT || EPI == EPI_DGRAD) {
         if (EPI == EPI_FWD_OUT && !e.C) return;
@@ -261,6 +265,42 @@ __device__ __forceinline__ void epilogue_block(const EpiArgs &e, int mb, int nb,
             const int m = rbase + (r & 3) + 8 * (r >> 2);
             if (m < e.m_limit) e.C[(size_t)m * e.ldc + n] = acc[r];
         }
+    }
+}
+
+// EPI_OUT_SPLIT, registers [R0, R0+4) of the wave's 32x32 block.  store: this k-slice's partial sums into its slab, agent-scope
+// write-through (complete in memory once the wave has drained vmcnt).  sum: the OUT_SPLITS partials of the tile, added in slice order
+// 0..3 whichever slice arrived last (the summation order of the two-launch form this replaces: the same bits), agent-scope loads.
+template <int R0>
+__device__ __forceinline__ void out_split_store(const EpiArgs &e, float *slab, int mb, int nb, const f32x16 &acc, int lane)
+{
+    const int n = nb + (lane & 31), rbase = mb + 4 * (lane >> 5);
+    if (n >= e.n_limit) return;
+#pragma unroll
+    for (int r = R0; r < R0 + 4; ++r) {
+        const int m = rbase + (r & 3) + 8 * (r >> 2);
+        if (m < e.m_limit) __hip_atomic_store(slab + (size_t)m * e.ldc + n, acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int R0>
+__device__ __forceinline__ void out_split_sum(const EpiArgs &e, const float *slab0, size_t stride, int mb, int nb, f32x16 &acc, int lane)
+{
+    const int n = nb + (lane & 31), rbase = mb + 4 * (lane >> 5);
+    if (n >= e.n_limit) return;
+    float p[OUT_SPLITS][4];
+#pragma unroll
+    for (int z = 0; z < OUT_SPLITS; ++z)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = R0 + rr, m = rbase + (r & 3) + 8 * (r >> 2), mc = m < e.m_limit ? m : e.m_limit - 1;   // (clamped: all 16 loads unconditional)
+            p[z][rr] = __hip_atomic_load(slab0 + z * stride + (size_t)mc * e.ldc + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        float s = p[0][rr];
+#pragma unroll
+        for (int z = 1; z < OUT_SPLITS; ++z) s += p[z][rr];
+        acc[R0 + rr] = s;
     }
 }
 
@@ -494,11 +534,12 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
     const int ks = wave / (WM * WN), wq = wave % (WM * WN), wm = wq / WN, wn = wq % WN;
     GemmArgs g = g_in;
     EpiArgs e = e_in;
-    if constexpr (EPI == EPI_PARTIAL) {      // this workgroup row's k-slice and output slab
+    constexpr int EPI_E = EPI == EPI_OUT_SPLIT ? EPI_FWD_OUT : EPI;      // the epilogue proper
+    if constexpr (EPI == EPI_PARTIAL || EPI == EPI_OUT_SPLIT) {      // this workgroup row's k-slice and output slab
         const size_t kz = (size_t)block_y * g.k_split;
         g.A += A_KC ? kz : kz * g.lda;
         g.B += B_KC ? kz : kz * g.ldb;
-        e.C += (size_t)block_y * g.slab_stride;
+        if constexpr (EPI == EPI_PARTIAL) e.C += (size_t)block_y * g.slab_stride;
     }
 
     // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous range of
@@ -562,14 +603,14 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) epilogue_fetch<EPI, 0, 16>(e, mb0 + i * 32, nb0 + j * 32, lane, pre[i][j]);
+            for (int j = 0; j < TN; ++j) epilogue_fetch<EPI_E, 0, 16>(e, mb0 + i * 32, nb0 + j * 32, lane, pre[i][j]);
     } else {
         static_assert(KS == 1 || (TM == 1 && TN == 1), "in-workgroup k-split needs one block per wave");
-        if (ks == 0) epilogue_fetch<EPI, 0, 16 / KS>(e, mb0, nb0, lane, pre[0][0]);
-        if (ks == 1) epilogue_fetch<EPI, 16 / KS, 16 / KS>(e, mb0, nb0, lane, pre[0][0]);
+        if (ks == 0) epilogue_fetch<EPI_E, 0, 16 / KS>(e, mb0, nb0, lane, pre[0][0]);
+        if (ks == 1) epilogue_fetch<EPI_E, 16 / KS, 16 / KS>(e, mb0, nb0, lane, pre[0][0]);
         if constexpr (KS == 4) {
-            if (ks == 2) epilogue_fetch<EPI, 8, 4>(e, mb0, nb0, lane, pre[0][0]);
-            if (ks == 3) epilogue_fetch<EPI, 12, 4>(e, mb0, nb0, lane, pre[0][0]);
+            if (ks == 2) epilogue_fetch<EPI_E, 8, 4>(e, mb0, nb0, lane, pre[0][0]);
+            if (ks == 3) epilogue_fetch<EPI_E, 12, 4>(e, mb0, nb0, lane, pre[0][0]);
         }
     }
 
@@ -674,18 +715,44 @@ static __device__ __forceinline__ void run(const GemmArgs &g_in, const EpiArgs &
         }
     }
 
+    // ---- split-K across workgroups in one launch (EPI_OUT_SPLIT): every slice writes its partial tile, drains, takes a ticket from the
+    // tile's word; the last of the OUT_SPLITS arrivals of this launch sums the slices and runs the output epilogue, the others are
+    // done.  Nobody waits for anybody.  (The ticket words only grow: OUT_SPLITS per launch; the slices of a tile are workgroups
+    // b, b + tiles, ... of the launch -- on one XCD, block index mod 8, whenever the tile count is a multiple of 8.)
+    bool finish = true;
+    if constexpr (EPI == EPI_OUT_SPLIT) {
+        static_assert(KS == 4 && OUT_SPLITS == 4, "one 32x32 block per workgroup, four registers of it per wave");
+        float *mine = g.ks_slab + (size_t)block_y * g.slab_stride;
+        if (ks == 0) out_split_store<0>(e, mine, mb0, nb0, acc[0][0], lane);
+        if (ks == 1) out_split_store<4>(e, mine, mb0, nb0, acc[0][0], lane);
+        if (ks == 2) out_split_store<8>(e, mine, mb0, nb0, acc[0][0], lane);
+        if (ks == 3) out_split_store<12>(e, mine, mb0, nb0, acc[0][0], lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                       // (also: every wave is past its reads of the exchange area)
+        unsigned *tk = reinterpret_cast<unsigned *>(smem);
+        if (tid == 0) *tk = __hip_atomic_fetch_add(g.ks_ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        finish = (*tk & (OUT_SPLITS - 1)) == OUT_SPLITS - 1;
+        if (finish) {
+            if (ks == 0) out_split_sum<0>(e, g.ks_slab, g.slab_stride, mb0, nb0, acc[0][0], lane);
+            if (ks == 1) out_split_sum<4>(e, g.ks_slab, g.slab_stride, mb0, nb0, acc[0][0], lane);
+            if (ks == 2) out_split_sum<8>(e, g.ks_slab, g.slab_stride, mb0, nb0, acc[0][0], lane);
+            if (ks == 3) out_split_sum<12>(e, g.ks_slab, g.slab_stride, mb0, nb0, acc[0][0], lane);
+        }
+    }
+
     if constexpr (KS == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                epilogue_block<EPI, 0, 16>(e, mb0 + i * 32, nb0 + j * 32, acc[i][j], lane, pre[i][j]);
-    } else {
-        if (ks == 0) epilogue_block<EPI, 0, 16 / KS>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
-        if (ks == 1) epilogue_block<EPI, 16 / KS, 16 / KS>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+                epilogue_block<EPI_E, 0, 16>(e, mb0 + i * 32, nb0 + j * 32, acc[i][j], lane, pre[i][j]);
+    } else if (finish) {
+        if (ks == 0) epilogue_block<EPI_E, 0, 16 / KS>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+        if (ks == 1) epilogue_block<EPI_E, 16 / KS, 16 / KS>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
         if constexpr (KS == 4) {
-            if (ks == 2) epilogue_block<EPI, 8, 4>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
-            if (ks == 3) epilogue_block<EPI, 12, 4>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+            if (ks == 2) epilogue_block<EPI_E, 8, 4>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
+            if (ks == 3) epilogue_block<EPI_E, 12, 4>(e, mb0, nb0, acc[0][0], lane, pre[0][0]);
         }
     }
     if (b + stride < g.tiles_m * g.tiles_n) __syncthreads();   // smem is reused by the next tile
@@ -854,54 +921,18 @@ __global__ void bp_fill_normal(float *buf, int ld, int width, int rows, uint32_t
     *reinterpret_cast<float4 *>(buf + r * ld + c) = o;
 }
 
-// Second half of a split-K output layer: out = sum_z slab[z] + bias; dEdX = scale*(out - targ)
-// (kernSubClean, DevFunc.cu:253-268).  One thread = 4 consecutive columns of one frame.
-// Everything the thread reads -- its four slab pieces, the bias, the targets -- is loaded up front in straight-line code: the launch
-// is pure latency, and with the slab count a run-time loop bound the compiler emitted six DEPENDENT round trips (slab, 3 x (slab,
-// wait, add), bias, targets), which was most of the launch's 5.3 us.
-static constexpr int OUT_SPLITS = 4;
-struct OutReduceArgs {
-    const float *slabs; size_t slab_stride; int M, ld, n_true;
-    const float *bias; float alpha; const float *targ; float scale; float *out, *dedx;
-};
-__device__ __forceinline__ void out_reduce_block(const OutReduceArgs &a, int block, int tx)
+// The narrow output layer's forward, split over OUT_SPLITS k-slices (EPI_OUT_SPLIT; workgroup b < n_gemm: slice b / tiles of tile
+// b % tiles) AND, in the same launch, the stacking of the NEXT bunch into the other staged tile (workgroups >= n_gemm; none if
+// st.nbx == 0): the layer is 320 workgroups of launch latency on a chip that is otherwise idle at that point of the step, so the next
+// bunch's bp_stage_bunch (5.1 us as its own launch in front of every bunch, round 3) rides along for free.  (Rounds 3-5 ran the layer
+// as two launches -- partial sums, then a reduce launch that carried the staging: 7.9 + 5.2 us at configs[1].)
+template <class K>
+__global__ __launch_bounds__(256, K::MIN_WG) void bp_out_split_stage(const GemmArgs g, const EpiArgs e, int n_gemm, const StageArgs st)
 {
-    const int c4 = block * 256 + tx, per_row = a.ld / 4;
-    if (c4 >= a.M * per_row) return;
-    const int m = c4 / per_row, n = (c4 % per_row) * 4;
-    const size_t i = (size_t)m * a.ld + n;
-    float4 p[OUT_SPLITS];
-#pragma unroll
-    for (int z = 0; z < OUT_SPLITS; ++z) p[z] = *reinterpret_cast<const float4 *>(a.slabs + z * a.slab_stride + i);
-    const float4 b = *reinterpret_cast<const float4 *>(a.bias + n);
-    const float4 t = *reinterpret_cast<const float4 *>(a.dedx ? a.targ + i : a.bias + n);      // (no targets without dEdX: any valid address)
-    float4 s = p[0];
-#pragma unroll
-    for (int z = 1; z < OUT_SPLITS; ++z) { s.x += p[z].x; s.y += p[z].y; s.z += p[z].z; s.w += p[z].w; }
-    float o[4] = {a.alpha * s.x + b.x, a.alpha * s.y + b.y, a.alpha * s.z + b.z, a.alpha * s.w + b.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (n + j >= a.n_true) o[j] = 0.0f;
-    if (a.out) *reinterpret_cast<float4 *>(a.out + i) = make_float4(o[0], o[1], o[2], o[3]);
-    if (a.dedx) {
-        float4 d = make_float4(a.scale * (o[0] - t.x), a.scale * (o[1] - t.y), a.scale * (o[2] - t.z), a.scale * (o[3] - t.w));
-        if (n + 0 >= a.n_true) d.x = 0.f;
-        if (n + 1 >= a.n_true) d.y = 0.f;
-        if (n + 2 >= a.n_true) d.z = 0.f;
-        if (n + 3 >= a.n_true) d.w = 0.f;
-        *reinterpret_cast<float4 *>(a.dedx + i) = d;
-    }
-}
-__global__ __launch_bounds__(256) void bp_out_reduce(const OutReduceArgs a)
-{
-    out_reduce_block(a, blockIdx.x, threadIdx.x);
-}
-// The reduce AND, in the same launch, the stacking of the NEXT bunch of a window chunk into the other staged tile
-// (workgroups >= n_reduce): the reduce is 80 workgroups of launch latency on a chip that is otherwise idle at that point of
-// the step, so the next bunch's bp_stage_bunch (5.1 us as its own launch in front of every bunch, round 3) rides along for free.
-__global__ __launch_bounds__(256) void bp_out_reduce_stage(const OutReduceArgs a, int n_reduce, const StageArgs st)
-{
-    if ((int)blockIdx.x < n_reduce) out_reduce_block(a, blockIdx.x, threadIdx.x);
-    else { const int e = blockIdx.x - n_reduce; stage_block(st, e % st.nbx, e / st.nbx, threadIdx.x); }
+    __shared__ __attribute__((aligned(16))) float smem[K::SMEM];
+    const int b = blockIdx.x;
+    if (b < n_gemm) { const int tiles = g.tiles_m * g.tiles_n; K::run(g, e, b % tiles, tiles, b / tiles, smem); }
+    else { const int i = b - n_gemm; stage_block(st, i % st.nbx, i / st.nbx, threadIdx.x); }
 }
 
 // Momentum update on a flat [W|b] gradient segment after the data-parallel sum

@@ -93,7 +93,9 @@ static int stage_blocks(const bp_handle *h, const StageArgs &a);
 static int bf_alloc(bp_handle *h, bf16_t **p, size_t n_halfs);
 static hipError_t bf_shadow(bp_handle *h, int l);
 
-enum { BF_OUT_KS = 4 };   // (measured at configs[4], us per launch: unsplit 17.7, 4 slices 13.3, 8 slices 13.8, 16 slices 33.3 -- the exchange of the partial tiles grows with the slice count; profiles/r06_bf16_out_split.txt)                                  // k slices of the bf16 output forward (bf_out_splits)
+// k slices of the bf16 output forward (bf_out_splits).  Measured at configs[4], us per launch: unsplit 17.7, 4 slices 13.3, 8 slices 13.8,
+// 16 slices 33.3 -- the exchange of the partial tiles grows with the slice count (profiles/r06_bf16_out_split.txt)
+enum { BF_OUT_KS = 4 };
 static bool bf_out_splits(const bp_handle *h);
 extern "C" int bp_create(const bp_config *cfg, const float *const *weights, const float *const *bias,
                          bp_handle **out)
@@ -151,13 +153,16 @@ extern "C" int bp_create(const bp_config *cfg, const float *const *weights, cons
     // a caller that only ever hands window chunks never pays for them)
     CK(dev_alloc(h, &h->out_dev, Bp * h->ld[L - 1]));
     // narrow output layer (e.g. 2048 -> 257): too few 32x32 tiles to fill 256 CUs, so its k range is
-    // split over 4 workgroup rows that write partial-sum slabs; bp_out_reduce finishes the layer
+    // split over 4 workgroups per tile that meet through partial-sum slabs (EPI_OUT_SPLIT, bp_kernels.h)
     if (h->ld[L - 1] <= 512 && h->ld[L - 2] >= 1024 && h->ld[L - 2] % 256 == 0) {
         h->out_splits = OUT_SPLITS;
         // (measured round 3: 8 / 16 k-slices with 64x64 workgroup tiles -- half the operand bytes per FLOP -- are no faster:
         // C2 step 0.2216 ms with 4 slices, 0.2204 with 8, 0.2237 with 16; the layer is launch/latency-bound)
         h->slab_stride = Bp * h->ld[L - 1];
         CK(dev_alloc(h, &h->slabs, h->slab_stride * h->out_splits));
+        float *tk = nullptr;
+        CK(dev_alloc(h, &tk, (Bp / 32) * (size_t)((h->ld[L - 1] + 31) / 32)));      // one ticket word per 32 x 32 tile (zeroed)
+        h->out_ticket = reinterpret_cast<unsigned *>(tk);
     }
     size_t goff = 0;
     for (int l = 1; l < L; ++l) {
@@ -294,26 +299,23 @@ hipError_t launch_fwd(bp_handle *h, hipStream_t st, int l, int M, const float *y
     e.scale = 2.0f / (float)h->Bg;                       // kernSubClean: 2.0f/rows (global rows under DP)
     if (h->out_splits > 1) {
         g.K = prev / h->out_splits; g.k_split = g.K; g.slab_stride = h->slab_stride;
-        e.C = h->slabs; e.ldc = cur;
+        g.ks_slab = h->slabs; g.ks_ticket = h->out_ticket;
         g.tiles_m = (M + 31) / 32; g.tiles_n = (cur + 31) / 32;
-        hipLaunchKernelGGL((bp_gemm<32, 32, 64, 1, 1, true, false, EPI_PARTIAL>),
-                           dim3(g.tiles_m * g.tiles_n, h->out_splits), dim3(256), 0, st, g, e);
-        hipError_t er = hipGetLastError();
-        if (er != hipSuccess) return er;
-        const int n4 = M * (cur / 4), n_reduce = (n4 + 255) / 256;
-        OutReduceArgs ra; memset(&ra, 0, sizeof(ra));
-        ra.slabs = h->slabs; ra.slab_stride = h->slab_stride; ra.M = M; ra.ld = cur; ra.n_true = h->s[l];
-        ra.bias = h->b[l]; ra.alpha = alpha; ra.targ = targ; ra.scale = e.scale; ra.out = out; ra.dedx = train ? h->dx[l] : (float *)nullptr;
+        e.C = train ? h->dx[l] : nullptr; e.ldc = cur;
+        e.aux = targ; e.ldaux = cur; e.aux2 = out; e.ldaux2 = cur;
+        using KOut = GemmKernel<32, 32, 64, 1, 1, true, false, EPI_OUT_SPLIT>;
+        const int n_gemm = g.tiles_m * g.tiles_n * OUT_SPLITS;
+        StageArgs sa; memset(&sa, 0, sizeof(sa));
+        int n_stage = 0;
         if (train && h->next_first >= 0 && st == h->stream) {
             // another staged bunch behind this one (window chunk, or stacked chunk with visible dropout): stack / copy (and mask, with the NEXT step's Philox position) that bunch
             // into the other tile from the spare workgroups of this launch
             const int tile = 1 - h->stage_cur;
-            const StageArgs sa = stage_args(h, h->next_first, h->B, true, tile, h->step + 1);
-            hipLaunchKernelGGL(bp_out_reduce_stage, dim3((unsigned)(n_reduce + stage_blocks(h, sa))), dim3(256), 0, st, ra, n_reduce, sa);
+            sa = stage_args(h, h->next_first, h->B, true, tile, h->step + 1);
+            n_stage = stage_blocks(h, sa);
             h->pre.valid = true; h->pre.first = h->next_first; h->pre.tile = tile; h->pre.step = h->step + 1; h->pre.gen = h->wgen;
-            return hipGetLastError();
         }
-        hipLaunchKernelGGL(bp_out_reduce, dim3((unsigned)n_reduce), dim3(256), 0, st, ra);
+        hipLaunchKernelGGL(bp_out_split_stage<KOut>, dim3((unsigned)(n_gemm + n_stage)), dim3(256), 0, st, g, e, n_gemm, sa);
         return hipGetLastError();
     }
     e.C = train ? h->dx[l] : nullptr; e.ldc = cur;

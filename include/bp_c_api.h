@@ -265,7 +265,7 @@ int bp_time_kernel(bp_handle *h, int which, int iters, float *avg_ms);
  * on the launch stream: avg_ms[BP_PROF_*] = average duration of one launch of that class AS IT RUNS INSIDE THE
  * STEP (previous event -> own event, i.e. the kernel plus the dependent-launch boundary in front of it),
  * launches_per_step[] = how many launches of the class a step makes.  Trains like bp_train_resident does. */
-enum { BP_PROF_FWD_L1 = 0, BP_PROF_FWD_HIDDEN = 1, BP_PROF_FWD_OUT = 2 /* split-K GEMM + reduce */, BP_PROF_DGRAD_OUT = 3,
+enum { BP_PROF_FWD_L1 = 0, BP_PROF_FWD_HIDDEN = 1, BP_PROF_FWD_OUT = 2 /* split-K GEMM with its reduce, one launch */, BP_PROF_DGRAD_OUT = 3,
        BP_PROF_DGRAD_HIDDEN = 4, BP_PROF_WGRAD = 5 /* every layer's wgrad + update: one grouped launch */, BP_PROF_KINDS = 6 };
 int bp_profile_step(bp_handle *h, int first_frame, int n_bunches, float *avg_ms, int *launches_per_step);
 /* Peaks measured on this device in this process: bare v_mfma_f32_32x32x2_f32 loop (TFLOP/s) and a float4

@@ -496,7 +496,7 @@ def test_window_chunk_equals_stacked_chunk(pkg, nat, dtype):
 @pytest.mark.parametrize("nat", [False, True])
 def test_window_bunches_prestaged_by_the_output_layer_launch(pkg, nat):
     """With a split-K output layer (hidden width >= 1024) the reduce launch of bunch i also stacks + masks bunch i+1 into the
-    second staged tile (bp_out_reduce_stage; Philox position of step i+1), so only the first bunch of a call is stacked by a
+    second staged tile (bp_out_split_stage; Philox position of step i+1), so only the first bunch of a call is stacked by a
     launch of its own.  Same weights, bit for bit, as the chunk handed over stacked by the host; chunks of 6 and 1 bunches,
     a second train call that starts in the middle of the resident chunk, CV at the end."""
     rs = np.random.default_rng(35)
