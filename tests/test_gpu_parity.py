@@ -100,6 +100,37 @@ def test_train_matches_oracle(pkg, oracle_mod, ls, B, nb, act, rule, wc, drop):
     g.close()
 
 
+def test_split_output_layer_slices_on_different_xcds_many_steps(pkg, oracle_mod, parity_record):
+    """The output layer's k-slices meet through slabs + a ticket word inside ONE launch (EPI_OUT_SPLIT, bp_kernels.h).  With a tile
+    count that is no multiple of 8 (80 frames x 257 outputs: 3 x 10 tiles) the four slices of a tile run on DIFFERENT XCDs, so what
+    the finisher reads was written through another L2, and from the second step on its own L2 may still hold last step's lines of
+    the same slab.  Sixty steps, Sigmoid (no ReLU decision that could blur the comparison), every step's partial sums feed the next:
+    plain 1e-4 against the oracle on everything, CV sum and forward outputs included."""
+    ls, B, nb = [300, 1024, 257], 80, 60
+    W, b = N.glorot_net(ls, seed=6, beta=1.0)
+    rng = np.random.default_rng(23)
+    x = rng.normal(size=(nb * B, ls[0])).astype(np.float32)
+    t = rng.normal(size=(nb * B, ls[-1])).astype(np.float32)
+    kw = dict(activation=1, momentum_rule=1)
+    g = _mk(pkg, ls, B, W, b, lr=0.5, m=0.5, wc=0.0, cap=nb * B, **kw)
+    o = oracle_mod.Oracle(ls, B, 0.5, 0.5, 0.0, W, b, **kw)
+    g.train(nb * B, x, t)
+    assert o.train(x, t) == nb
+    w, bb = g.get_weights()
+    dw, dbb = g.get_deltas()
+    errs = {}
+    for l in range(1, len(ls)):
+        errs.update({"W%d" % l: relerr(w[l], o.W[l]), "b%d" % l: relerr(bb[l], o.b[l]),
+                     "dW%d" % l: relerr(dw[l], o.dW[l]), "db%d" % l: relerr(dbb[l], o.db[l])})
+    errs["forward"] = relerr(g.forward(x[:B + 7]), o.forward(x[:B + 7]))
+    cg, co = g.CrossValid(3 * B + 11, x, t), o.crossvalid(x[:3 * B + 11], t[:3 * B + 11])
+    errs["cv_sum"] = abs(cg - co) / abs(co)
+    parity_record(case="300-1024-257 Sigmoid, 80-frame bunches, 60 steps", bar="1e-4 plain", errors=errs)
+    print(errs)
+    assert max(errs.values()) < TOL, errs
+    g.close()
+
+
 def test_dropout_mask_is_the_oracle_philox_stream(pkg, oracle_mod):
     """With lr=0 nothing moves, so check the mask through its effect: train 1 step with weights
     that make layer-1 outputs strictly positive, then compare W after the step bit-pattern-wise
