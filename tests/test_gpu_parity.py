@@ -131,6 +131,36 @@ def test_split_output_layer_slices_on_different_xcds_many_steps(pkg, oracle_mod,
     g.close()
 
 
+@pytest.mark.parametrize("ls,B,dtype,steps", [
+    ([2827, 2048, 2048, 2048, 257], 256, 0, 1500),              # C2: 80 output tiles x 4 slices, ticket + last-arriver sum in every step
+    ([300, 1024, 257], 80, 0, 1500),                            # 30 output tiles: the slices of a tile on different XCDs
+    ([300, 1024, 1024, 257], 256, 1, 600),                      # bf16: split-k output forward (40 tiles x 4 slices)
+])
+def test_two_runs_of_many_steps_agree_bit_for_bit(pkg, ls, B, dtype, steps):
+    """The launches that combine partial results inside ONE kernel (output layer: k-slices of a tile meet through slabs and a ticket
+    word, the last arriver sums them in slice order) must not depend on who arrives when.  Two handles, same weights, same resident
+    synthetic chunk, same seed, `steps` training steps each with dropout on (so the next bunch's staging rides along too): every
+    weight and every momentum word identical.  A finisher that read a partial tile before it was visible would show up here as a
+    mismatch within the first few hundred steps."""
+    W, b = N.glorot_net(ls, seed=2, beta=0.5)
+    kw = dict(dropoutflag=1, visible_omit=0.1, hid_omit=0.2, seed=11, compute_dtype=dtype)
+    n = 50 * B
+    res = []
+    for _ in range(2):
+        g = _mk(pkg, ls, B, W, b, lr=0.01, m=0.5, cap=n, **kw)
+        g.fill_chunk_synthetic(n, 5)
+        for _ in range(steps // 50):
+            g.train_resident(0, n)
+        w, bb = g.get_weights()
+        dw, dbb = g.get_deltas()
+        res.append((w, bb, dw, dbb))
+        g.close()
+    for l in range(1, len(ls)):
+        for a, c in zip(res[0], res[1]):
+            assert np.array_equal(a[l], c[l]), (ls, l)
+        assert np.isfinite(res[0][0][l]).all()
+
+
 def test_dropout_mask_is_the_oracle_philox_stream(pkg, oracle_mod):
     """With lr=0 nothing moves, so check the mask through its effect: train 1 step with weights
     that make layer-1 outputs strictly positive, then compare W after the step bit-pattern-wise
