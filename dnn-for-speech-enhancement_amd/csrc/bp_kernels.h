@@ -827,13 +827,24 @@ __device__ __forceinline__ void stage_rows_block(const StageArgs &a, int bx, int
     for (int j = 0; j < 4; ++j)
         v[j] = *reinterpret_cast<const float4 *>(a.fea + (size_t)(r0 + j < a.rows ? r0 + j : a.rows - 1) * a.fea_dim + c);   // (clamped, unconditional: four loads in flight)
     if (a.thresh) {
-#pragma unroll
+        // one Philox block per column; the loop is NOT unrolled (four inlined copies of the ten rounds were 3 KB of a launch whose code
+        // shares the instruction caches with the rest of the step): the decisions are collected as bits
+        // (bit 4k + j: row j of column k) and applied with constant indices
+        uint32_t drop = 0;
+#pragma unroll 1
         for (int k = 0; k < 4; ++k) {
             if (c + k >= a.width) break;
             uint32_t w[4];
             drop_words4(w, r0, c + k, a.frame_off, (uint32_t)a.width, 0u, a.step, a.seed_lo, a.seed_hi);
+            const uint32_t m = (w[0] < a.thresh ? 1u : 0u) | (w[1] < a.thresh ? 2u : 0u) | (w[2] < a.thresh ? 4u : 0u) | (w[3] < a.thresh ? 8u : 0u);
+            drop |= m << (4 * k);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (w[j] < a.thresh) (&v[j].x)[k] = 0.0f;
+        for (int j = 0; j < 4; ++j) {
+            if (drop & (1u << (0 + j))) v[j].x = 0.0f;
+            if (drop & (1u << (4 + j))) v[j].y = 0.0f;
+            if (drop & (1u << (8 + j))) v[j].z = 0.0f;
+            if (drop & (1u << (12 + j))) v[j].w = 0.0f;
         }
     }
 #pragma unroll
